@@ -1,0 +1,162 @@
+/*
+ * pixell_hip.h -- C ABI of libpixell_hip.so: MI355X (gfx950) kernels for the Pixell.jl CAR
+ * pixel<->sky hot path (pix2sky / sky2pix evaluators, posmap, CAR->CAR bilinear reprojection and
+ * scattered bilinear sampling, Float64).
+ *
+ * This is the drop-in boundary.  The reference (pure Julia) has no plugin ABI of its own; each entry
+ * below names the reference method it replaces (file:line under /root/reference/src/).  A Julia host
+ * binds these with `ccall((:sym, libpixell_hip), Cint, (...), ...)` in the style the reference already
+ * uses for libsharp/wcslib (transforms.jl:185-194, arbitrary_wcs.jl:41-43); see INTEGRATION.md.
+ *
+ * Conventions
+ *   - Plain C types only.  All data pointers are DEVICE pointers (HBM) unless named host_*.
+ *   - Every entry returns 0 on success or a negative code (PXL_E*); it never throws, exits or prints.
+ *     pxl_last_error() returns the thread-local message of the last failing call.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Entries only enqueue work;
+ *     they never synchronise, allocate or free caller-visible memory (plans own their own tables).
+ *   - Arrays are Julia column-major: maps are (nx, ny[, nc]) with RA the contiguous axis; coordinate
+ *     batches are 2xN, i.e. interleaved (c1, c2) pairs (car_proj.jl:102-107).  Pixel coordinates are
+ *     1-based Float64, angles are radians.
+ *   - Arithmetic is IEEE double with NO fma contraction, op-for-op the reference's, so pix<->sky
+ *     results are bit-identical to the reference CPU path.
+ */
+#ifndef PIXELL_HIP_H
+#define PIXELL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PXL_VERSION 100   /* 0.1.0 */
+
+/* CarClenshawCurtis{Float64} / CarFejer1{Float64}: projections/car_proj.jl:7-19 (isbits, 56 bytes).
+ * Also used for Gnomonic{Float64} (projections/tan_proj.jl:4-9), which has the same fields. */
+typedef struct pxl_car_wcs {
+    double cdelt[2];
+    double crpix[2];
+    double crval[2];
+    double unit;      /* conversion factor to radians; pi/180 for degree WCS (enmap_geom.jl:18) */
+} pxl_car_wcs;
+
+/* error codes */
+#define PXL_OK         0
+#define PXL_EINVAL   (-22)   /* bad argument (null pointer, negative size, window outside the map) */
+#define PXL_ENOMEM   (-12)   /* device allocation failed (plan creation only) */
+#define PXL_EHIP     (-5)    /* a HIP runtime call failed; message has hipGetErrorString */
+#define PXL_ENODEV   (-19)   /* no gfx950 device / kernel image not loadable */
+
+/* `safe` keyword of the reference's array evaluators */
+#define PXL_WRAP_NONE    0   /* safe=false */
+#define PXL_WRAP_REWIND  1   /* per-element rewind (what scalar pix2sky does, car_proj.jl:148-150) */
+#define PXL_WRAP_UNWIND  2   /* safe=true on 2xN arrays: rewind then unwrap along N (car_proj.jl:110-112) */
+
+/* the reference's three sky2pix roundings (they differ in the last bit) */
+#define PXL_FORM_RECIP     0 /* sky2pix!(2xN):      i0 + (a-a0)*(1/d), period abs(2pi/d)      car_proj.jl:165-193 */
+#define PXL_FORM_DIV       1 /* sky2pix(ra, dec):   i0 + (a-a0)/d,     period abs(2pi/d)      car_proj.jl:220-234 */
+#define PXL_FORM_RECIP_AV  2 /* sky2pix(ras, decs): i0 + (a-a0)*(1/d), period abs(2pi*(1/d))  car_proj.jl:235-252 */
+
+int         pxl_version(void);
+/* copies the calling thread's last error message (NUL-terminated, truncated to n) and returns its length */
+size_t      pxl_last_error(char* buf, size_t n);
+/* number of visible HIP devices, or a negative error */
+int         pxl_device_count(void);
+
+/* ---- pix2sky!(shape, wcs::AbstractCARWCS, pixcoords::2xN, skycoords::2xN; safe)   car_proj.jl:92-115
+ *      In-place (pix == sky) is allowed.  wrap_mode: PXL_WRAP_NONE | _REWIND | _UNWIND.              */
+int pxl_pix2sky_car_f64(const pxl_car_wcs* wcs, int64_t n, const double* pix2xN, double* sky2xN,
+                        int wrap_mode, void* stream);
+
+/* ---- pix2sky(shape, wcs, ra_pixel, dec_pixel; safe) broadcast over two N-vectors   car_proj.jl:141-152
+ *      safe != 0 -> rewind(ra), rewind(dec).                                                         */
+int pxl_pix2sky_car_soa_f64(const pxl_car_wcs* wcs, int64_t n, const double* ipix, const double* jpix,
+                            double* ra, double* dec, int safe, void* stream);
+
+/* ---- sky2pix!(shape, wcs, skycoords::2xN, pixcoords::2xN; safe)                    car_proj.jl:165-193
+ *      form = PXL_FORM_RECIP reproduces it bit-for-bit; the other forms are exposed for completeness. */
+int pxl_sky2pix_car_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64_t n, const double* sky2xN,
+                        double* pix2xN, int safe, int form, void* stream);
+
+/* ---- sky2pix(shape, wcs, ra::AV, dec::AV; safe)   (form = PXL_FORM_RECIP_AV)        car_proj.jl:235-252
+ *      sky2pix(shape, wcs, ra::Number, dec::Number) broadcast (form = PXL_FORM_DIV)   car_proj.jl:220-234 */
+int pxl_sky2pix_car_soa_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64_t n, const double* ra,
+                            const double* dec, double* ipix, double* jpix, int safe, int form, void* stream);
+
+/* ---- posmap(shape, wcs)                                                             enmap_ops.jl:190-203
+ *      Writes rows [row0, row0+nrows) (0-based) of the (nx, ny) RA and DEC maps; ra/dec each hold
+ *      nx*nrows doubles.  The reference always uses safe=true (scalar pix2sky -> rewind).             */
+int pxl_posmap_car_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64_t row0, int64_t nrows,
+                       double* ra, double* dec, int safe, void* stream);
+
+/* ---- pixareamap!(pixareas)                                                          enmap_ops.jl:124-138
+ *      Fills rows [row0, row0+nrows) of an (nx, ny) map with the per-row pixel area (steradians).     */
+int pxl_pixareamap_car_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64_t row0, int64_t nrows,
+                           double* area, void* stream);
+
+/* ---- Gnomonic evaluators over N-vectors                                             tan_proj.jl:44-75
+ *      (the reference has scalar methods only; posmap(shape, ::Gnomonic) loops them).                 */
+int pxl_sky2pix_tan_f64(const pxl_car_wcs* wcs, int64_t n, const double* ra, const double* dec,
+                        double* ipix, double* jpix, void* stream);
+int pxl_pix2sky_tan_f64(const pxl_car_wcs* wcs, int64_t n, const double* ipix, const double* jpix,
+                        double* ra, double* dec, void* stream);
+int pxl_posmap_tan_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64_t row0, int64_t nrows,
+                       double* ra, double* dec, void* stream);
+
+/* ---- Bilinear reprojection CAR -> CAR.  NOT in the reference: the composite
+ *      posmap(out) [enmap_ops.jl:190-203, safe=false] o sky2pix(in) [car_proj.jl:220-234, safe=true]
+ *      o 2x2 gather + lerp, defined by oracle/pixell_oracle.c.
+ *
+ *      A plan holds the separable coordinate tables (nx_out + ny_out entries) in device memory.
+ *      src holds rows [src_row0, src_row0+src_nrows) of every component plane of the (nx, ny, nc)
+ *      source map: (nx, src_nrows, nc) column-major; dst receives rows [dst_row0, dst_row0+dst_nrows)
+ *      of the (nx_out, ny_out, nc) output: (nx_out, dst_nrows, nc).  Full maps: row0 = 0, nrows = ny.
+ *      Windows are how a declination strip (+ halo rows) of a sharded map is described without
+ *      changing a single bit of the coordinate arithmetic.                                          */
+typedef struct pxl_reproject_plan pxl_reproject_plan;
+
+int pxl_reproject_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[3],
+                              int64_t src_row0, int64_t src_nrows,
+                              const pxl_car_wcs* wcs_out, const int64_t shape_out[2],
+                              int64_t dst_row0, int64_t dst_nrows,
+                              pxl_reproject_plan** plan);
+/* enqueue table build + reprojection of all nc components on `stream` */
+int pxl_reproject_execute(pxl_reproject_plan* plan, const double* src, double* dst, void* stream);
+/* as above but only output rows [r0, r0+nr) RELATIVE to the plan's dst window (for interior/boundary
+ * splitting while a halo is in flight); tables must have been built by a previous execute/build.    */
+int pxl_reproject_build_tables(pxl_reproject_plan* plan, void* stream);
+int pxl_reproject_execute_rows(pxl_reproject_plan* plan, const double* src, double* dst,
+                               int64_t r0, int64_t nr, void* stream);
+/* source rows [lo, hi) (0-based, absolute) that the plan's dst window reads (host computation,
+ * same arithmetic as the device tables) -- what a shard must hold, i.e. strip + halo.               */
+int pxl_reproject_plan_src_rows(const pxl_reproject_plan* plan, int64_t* lo, int64_t* hi);
+/* output rows (relative to the dst window, [lo, hi)) whose stencil lies entirely inside source rows
+ * [have_lo, have_hi) -- the interior that can start before a halo arrives.                           */
+int pxl_reproject_plan_rows_covered(const pxl_reproject_plan* plan, int64_t have_lo, int64_t have_hi,
+                                    int64_t* lo, int64_t* hi);
+/* tuning knob for benchmarking: 0 = auto, 1 = force the direct-gather kernel, 2 = force staged */
+int pxl_reproject_plan_set_variant(pxl_reproject_plan* plan, int variant);
+int pxl_reproject_plan_destroy(pxl_reproject_plan* plan);
+
+/* one-shot convenience (creates a plan, executes, synchronises `stream`, destroys) */
+int pxl_reproject_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], const double* src,
+                                   const pxl_car_wcs* wcs_out, const int64_t shape_out[2], double* dst,
+                                   void* stream);
+
+/* ---- Scattered bilinear sample: (x, y) = sky2pix!(shape_in, wcs_in, sky2xN; safe=true)
+ *      [car_proj.jl:165-193] then the same 2x2 gather + lerp.  out is (n, nc) column-major.          */
+int pxl_sample_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], const double* src,
+                                int64_t src_row0, int64_t src_nrows,
+                                int64_t n, const double* sky2xN, double* out, void* stream);
+
+/* ---- synthetic inputs (benchmark plumbing, deterministic counter-based generator):
+ *      fill n doubles with N(0,1) (kind 0) or U[0,1) (kind 1) from splitmix64(seed, index+offset);
+ *      uniform-on-sphere points (ra = 2pi*u1 - pi, dec = asin(2*u2 - 1)) as a 2xN batch.             */
+int pxl_fill_random_f64(double* dst, int64_t n, uint64_t seed, uint64_t offset, int kind, void* stream);
+int pxl_fill_sphere_points_f64(double* sky2xN, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIXELL_HIP_H */

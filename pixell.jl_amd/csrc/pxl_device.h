@@ -1,0 +1,108 @@
+// pxl_device.h -- device-side arithmetic shared by every kernel of libpixell_hip.so.
+//
+// Each helper restates one piece of the reference's Float64 arithmetic (file:line under
+// /root/reference/src/).  The translation unit is compiled with -ffp-contract=off, so every `a + b * c`
+// below is a separate v_mul_f64 / v_add_f64, exactly like the fmul/fadd Julia emits.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pixell_hip.h"
+
+#define PXL_PI_D     3.141592653589793    // Float64(pi)
+#define PXL_TWOPI_D  6.283185307179586    // Julia's `2pi` == 2 * Float64(pi)
+
+namespace pxl {
+
+// Julia Base.mod(x::Float64, y::Float64): r = rem(x, y); r == 0 -> copysign(r, y);
+// (r > 0) xor (y > 0) -> r + y; else r.   fmod is exact, so this is bit-identical on any IEEE target.
+__host__ __device__ inline double jl_mod(double x, double y) {
+    double r = fmod(x, y);
+    if (r == 0.0) return copysign(r, y);
+    if ((r > 0.0) != (y > 0.0)) return r + y;
+    return r;
+}
+
+// rewind, enmap_ops.jl:10-13: ref + mod(a - ref + period/2, period) - period/2, left to right.
+__host__ __device__ inline double rewind(double a, double period, double ref) {
+    double half = period / 2;
+    return (ref + jl_mod((a - ref) + half, period)) - half;
+}
+
+// Pre-multiplied WCS scalars: the prologues of car_proj.jl:95-98 and :168-173.
+struct CarAffine {
+    double a0, d0;     // crval .* unit
+    double da, dd;     // cdelt .* unit
+    double ia0, id0;   // crpix
+};
+__host__ __device__ inline CarAffine car_affine(const pxl_car_wcs& w) {
+    CarAffine c;
+    c.a0 = w.crval[0] * w.unit; c.d0 = w.crval[1] * w.unit;
+    c.da = w.cdelt[0] * w.unit; c.dd = w.cdelt[1] * w.unit;
+    c.ia0 = w.crpix[0]; c.id0 = w.crpix[1];
+    return c;
+}
+
+// pix -> sky, car_proj.jl:104-105 / :146-147
+__host__ __device__ inline double p2s_ra(const CarAffine& c, double i)  { return c.a0 + (i - c.ia0) * c.da; }
+__host__ __device__ inline double p2s_dec(const CarAffine& c, double j) { return c.d0 + (j - c.id0) * c.dd; }
+
+// sky -> pix in the reference's three roundings (see PXL_FORM_* in pixell_hip.h)
+struct Sky2Pix {
+    CarAffine c;
+    double rda, rdd;   // 1/da, 1/dd            car_proj.jl:173
+    double cx, cy;     // shape[1:2] ./ 2 .+ 1   car_proj.jl:186
+    double px, py;     // pixel periods          car_proj.jl:187 / :229-230 / :247-248
+    int form, safe;
+};
+__host__ __device__ inline Sky2Pix sky2pix_setup(const pxl_car_wcs& w, int64_t nx, int64_t ny, int safe, int form) {
+    Sky2Pix s;
+    s.c = car_affine(w);
+    s.rda = 1 / s.c.da; s.rdd = 1 / s.c.dd;
+    s.cx = (double)nx / 2 + 1; s.cy = (double)ny / 2 + 1;
+    if (form == PXL_FORM_RECIP_AV) { s.px = fabs(PXL_TWOPI_D * s.rda); s.py = fabs(PXL_TWOPI_D * s.rdd); }
+    else                           { s.px = fabs(PXL_TWOPI_D / s.c.da); s.py = fabs(PXL_TWOPI_D / s.c.dd); }
+    s.form = form; s.safe = safe;
+    return s;
+}
+__host__ __device__ inline double s2p_x(const Sky2Pix& s, double a) {
+    double ix = (s.form == PXL_FORM_DIV) ? s.c.ia0 + (a - s.c.a0) / s.c.da : s.c.ia0 + (a - s.c.a0) * s.rda;
+    return s.safe ? rewind(ix, s.px, s.cx) : ix;
+}
+__host__ __device__ inline double s2p_y(const Sky2Pix& s, double d) {
+    double iy = (s.form == PXL_FORM_DIV) ? s.c.id0 + (d - s.c.d0) / s.c.dd : s.c.id0 + (d - s.c.d0) * s.rdd;
+    return s.safe ? rewind(iy, s.py, s.cy) : iy;
+}
+
+// Split a 1-based Float64 pixel coordinate into integer cell + fraction.  The cell index is clamped to
+// +-2^30 so it fits an int32 table entry; anything that far out reads as zero taps anyway.
+#define PXL_CELL_LIMIT 1073741824.0
+__host__ __device__ inline void split_cell(double x, int32_t* cell, double* frac) {
+    double f = floor(x);
+    *frac = x - f;
+    f = fmin(fmax(f, -PXL_CELL_LIMIT), PXL_CELL_LIMIT);
+    *cell = (int32_t)f;
+}
+
+// Source map view used by the direct-gather paths (oracle: tap()/bilerp() in oracle/pixell_oracle.c).
+struct SrcView {
+    const double* plane;   // first resident row of this component plane
+    int64_t nx, ny;        // full map size
+    int64_t row0, nrows;   // resident rows [row0, row0 + nrows), 0-based
+    int periodic;          // RA taps wrap modulo nx
+};
+__device__ inline double tap(const SrcView& m, int64_t i, int64_t j) {   // i, j 1-based
+    if (j < 1 || j > m.ny) return 0.0;
+    int64_t jr = j - 1 - m.row0;
+    if (jr < 0 || jr >= m.nrows) return 0.0;
+    if (m.periodic) { i = (i - 1) % m.nx; if (i < 0) i += m.nx; i += 1; }
+    else if (i < 1 || i > m.nx) return 0.0;
+    return m.plane[jr * m.nx + (i - 1)];
+}
+__device__ inline double bilerp_cells(const SrcView& m, int64_t i0, double fx, int64_t j0, double fy) {
+    double top = (1 - fx) * tap(m, i0, j0) + fx * tap(m, i0 + 1, j0);
+    double bot = (1 - fx) * tap(m, i0, j0 + 1) + fx * tap(m, i0 + 1, j0 + 1);
+    return (1 - fy) * top + fy * bot;
+}
+
+}  // namespace pxl

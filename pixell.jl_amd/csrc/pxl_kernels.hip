@@ -1,0 +1,981 @@
+// pxl_kernels.hip -- gfx950 kernels + C ABI of libpixell_hip.so (see include/pixell_hip.h).
+//
+// Every kernel here is HBM-bound (streams or gathers of Float64); none is GEMM-shaped, so there is
+// no MFMA.  The design rules are the memory ones: 16 B per lane coalesced loads/stores, source rows
+// staged through LDS once per output tile, XCD-aware tile order so neighbouring tiles share an L2.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared   (see build.py)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "pxl_device.h"
+
+using namespace pxl;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(PXL_EHIP, "%s: %s", #expr, hipGetErrorString(e_));  \
+    } while (0)
+
+static int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(PXL_EHIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return PXL_OK;
+}
+
+static bool wcs_ok(const pxl_car_wcs* w) {
+    if (!w) return false;
+    for (int k = 0; k < 2; ++k)
+        if (!std::isfinite(w->cdelt[k]) || !std::isfinite(w->crpix[k]) || !std::isfinite(w->crval[k]) ||
+            w->cdelt[k] == 0.0)
+            return false;
+    return std::isfinite(w->unit) && w->unit != 0.0;
+}
+
+// Grid for 1-D streaming kernels: enough 256-thread blocks to fill 256 CUs x 8, grid-stride the rest.
+static inline unsigned stream_grid(int64_t work_items, int block) {
+    int64_t nb = (work_items + block - 1) / block;
+    if (nb < 1) nb = 1;
+    if (nb > 256 * 16) nb = 256 * 16;
+    return (unsigned)nb;
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise evaluators (A9-A13): one (c1, c2) pair = 16 B in, 16 B out per lane
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pix2sky_pairs(CarAffine c, int64_t n, const double2* pix,
+                                                       double2* sky, int rewind_mode) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        double2 p = pix[k];
+        double a = p2s_ra(c, p.x);
+        double d = p2s_dec(c, p.y);
+        if (rewind_mode) { a = rewind(a, PXL_TWOPI_D, 0.0); d = rewind(d, PXL_TWOPI_D, 0.0); }
+        sky[k] = make_double2(a, d);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pix2sky_soa(CarAffine c, int64_t n, const double* __restrict__ ip,
+                                                     const double* __restrict__ jp, double* __restrict__ ra,
+                                                     double* __restrict__ dec, int safe) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        double a = p2s_ra(c, ip[k]);
+        double d = p2s_dec(c, jp[k]);
+        if (safe) { a = rewind(a, PXL_TWOPI_D, 0.0); d = rewind(d, PXL_TWOPI_D, 0.0); }
+        ra[k] = a; dec[k] = d;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sky2pix_pairs(Sky2Pix s, int64_t n, const double2* sky,
+                                                       double2* pix) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        double2 v = sky[k];
+        pix[k] = make_double2(s2p_x(s, v.x), s2p_y(s, v.y));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sky2pix_soa(Sky2Pix s, int64_t n, const double* __restrict__ ra,
+                                                     const double* __restrict__ dec, double* __restrict__ ip,
+                                                     double* __restrict__ jp) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        ip[k] = s2p_x(s, ra[k]);
+        jp[k] = s2p_y(s, dec[k]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// unwind! (A8, car_proj.jl:110-112 -> enmap_ops.jl:26-32): rewind, then DSP.unwrap along the point axis.
+//   y[0] = m[0];  y[k] = m[k] - rint((m[k] - y[k-1]) / P) * P            (sequential recurrence)
+// Every m[k] lies in [-P/2, P/2] after rewind.  The recurrence is carried by ONE wave per coordinate
+// row: lanes hold consecutive 64-point blocks and the wave walks the array once; within a block the
+// dependency is resolved with an exact replay by lane 0 .. 63 (a wave-serial scan: 64 dependent steps
+// per 64 points, but all memory traffic is coalesced and overlapped).  This keeps the reference's
+// floating-point recurrence bit-for-bit, which a re-associated parallel scan would not.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_unwind_rows(int64_t n, double* __restrict__ sky, double period, double ref) {
+    // blockIdx.x = coordinate row (0: RA, 1: DEC); element k of row r sits at sky[2*k + r]
+    const int row = blockIdx.x;
+    const int lane = threadIdx.x;
+    double prev = 0.0;
+    bool have_prev = false;
+    for (int64_t base = 0; base < n; base += 64) {
+        int64_t k = base + lane;
+        double m = 0.0;
+        if (k < n) m = rewind(sky[2 * k + row], period, ref) - ref;
+        // serial replay across the 64 lanes of this block
+        double y = m;
+        int cnt = (int)((n - base) < 64 ? (n - base) : 64);
+        for (int l = 0; l < cnt; ++l) {
+            double ml = __shfl(m, l, 64);
+            double yl = have_prev ? ml - rint((ml - prev) / period) * period : ml;
+            prev = yl;
+            have_prev = true;
+            if (lane == l) y = yl;
+        }
+        if (k < n) sky[2 * k + row] = y + ref;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// posmap (A15) / pixareamap (N4): write-only maps.  Lane = 2 adjacent RA pixels (16 B stores).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_posmap_car(CarAffine c, int64_t nx, int64_t row0, int64_t nrows,
+                                                    double* __restrict__ ra, double* __restrict__ dec, int safe) {
+    const int64_t npair = (nx + 1) / 2;
+    const int64_t total = npair * nrows;
+    const bool vec = ((nx & 1) == 0) && ((((uintptr_t)ra | (uintptr_t)dec) & 15) == 0);
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        int64_t jr = t / npair;
+        int64_t i = (t - jr * npair) * 2;            // 0-based column of the pair
+        double d = p2s_dec(c, (double)(row0 + jr + 1));
+        double a0 = p2s_ra(c, (double)(i + 1));
+        double a1 = p2s_ra(c, (double)(i + 2));
+        if (safe) {
+            d = rewind(d, PXL_TWOPI_D, 0.0);
+            a0 = rewind(a0, PXL_TWOPI_D, 0.0);
+            a1 = rewind(a1, PXL_TWOPI_D, 0.0);
+        }
+        int64_t o = jr * nx + i;
+        if (vec) {
+            *reinterpret_cast<double2*>(ra + o) = make_double2(a0, a1);
+            *reinterpret_cast<double2*>(dec + o) = make_double2(d, d);
+        } else {
+            ra[o] = a0; dec[o] = d;
+            if (i + 1 < nx) { ra[o + 1] = a1; dec[o + 1] = d; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pixareamap_car(CarAffine c, int64_t nx, int64_t row0, int64_t nrows,
+                                                        double* __restrict__ area) {
+    const int64_t npair = (nx + 1) / 2;
+    const int64_t total = npair * nrows;
+    const bool vec = ((nx & 1) == 0) && (((uintptr_t)area & 15) == 0);
+    const double da = fabs(c.da);
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        int64_t jr = t / npair;
+        int64_t i = (t - jr * npair) * 2;
+        double row = (double)(row0 + jr + 1);
+        // enmap_ops.jl:131-134: dec of the two pixel edges, sorted, clamped to the poles
+        double e0 = p2s_dec(c, row - 0.5), e1 = p2s_dec(c, row + 0.5);
+        double d1 = fmin(e0, e1), d2 = fmax(e0, e1);
+        d1 = fmax(-PXL_PI_D / 2, d1); d2 = fmin(PXL_PI_D / 2, d2);
+        double v = (sin(d2) - sin(d1)) * da;
+        int64_t o = jr * nx + i;
+        if (vec) *reinterpret_cast<double2*>(area + o) = make_double2(v, v);
+        else { area[o] = v; if (i + 1 < nx) area[o + 1] = v; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gnomonic (A16), tan_proj.jl:44-75
+// ------------------------------------------------------------------------------------------------
+struct TanParams { double scale, unit, a0, d0, sd0, cd0, cpx, cpy; };
+static TanParams tan_setup(const pxl_car_wcs& w) {
+    TanParams t;
+    t.scale = 1.0 / w.cdelt[0];
+    t.unit = w.unit;
+    t.a0 = w.crval[0] * (PXL_PI_D / 180);   // deg2rad.(wcs.crval), tan_proj.jl:47
+    t.d0 = w.crval[1] * (PXL_PI_D / 180);
+    t.sd0 = sin(t.d0); t.cd0 = cos(t.d0);
+    t.cpx = w.crpix[0]; t.cpy = w.crpix[1];
+    return t;
+}
+__device__ inline void tan_sky2pix(const TanParams& t, double a, double d, double* x, double* y) {
+    double A = cos(d) * cos(a - t.a0);
+    double F = t.scale / t.unit / (t.sd0 * sin(d) + A * t.cd0);
+    double LINE = -F * (t.cd0 * sin(d) - A * t.sd0);
+    double SAMPLE = -F * cos(d) * sin(a - t.a0);
+    *x = t.cpx - SAMPLE;
+    *y = t.cpy - LINE;
+}
+__device__ inline void tan_pix2sky(const TanParams& t, double i, double j, double* a, double* d) {
+    double X = (t.cpx - i) * t.unit / t.scale;
+    double Y = (t.cpy - j) * t.unit / t.scale;
+    double D = atan(sqrt(X * X + Y * Y));
+    double B = atan2(-X, Y);
+    double sD = sin(D), cD = cos(D), cB = cos(B);
+    double XX = t.sd0 * sD * cB + t.cd0 * cD;
+    double YY = sD * sin(B);
+    *a = t.a0 + atan2(YY, XX);
+    *d = asin(t.sd0 * cD - t.cd0 * sD * cB);
+}
+__global__ __launch_bounds__(256) void k_sky2pix_tan(TanParams t, int64_t n, const double* __restrict__ ra,
+                                                     const double* __restrict__ dec, double* __restrict__ x,
+                                                     double* __restrict__ y) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride)
+        tan_sky2pix(t, ra[k], dec[k], &x[k], &y[k]);
+}
+__global__ __launch_bounds__(256) void k_pix2sky_tan(TanParams t, int64_t n, const double* __restrict__ ip,
+                                                     const double* __restrict__ jp, double* __restrict__ ra,
+                                                     double* __restrict__ dec) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride)
+        tan_pix2sky(t, ip[k], jp[k], &ra[k], &dec[k]);
+}
+__global__ __launch_bounds__(256) void k_posmap_tan(TanParams t, int64_t nx, int64_t row0, int64_t nrows,
+                                                    double* __restrict__ ra, double* __restrict__ dec) {
+    const int64_t total = nx * nrows;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += stride) {
+        int64_t jr = k / nx, i = k - jr * nx;
+        tan_pix2sky(t, (double)(i + 1), (double)(row0 + jr + 1), &ra[k], &dec[k]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Reprojection (R1).
+// ------------------------------------------------------------------------------------------------
+// Separable tables: for output column i (0-based ic) the source cell xi0[ic] (1-based int) and fraction
+// xfx[ic]; same for rows.  (a, d) = pix2sky(out; safe=false) [car_proj.jl:146-147];
+// (x, y) = sky2pix(in; safe=true), division form [car_proj.jl:225-231].
+__global__ __launch_bounds__(256) void k_build_tables(CarAffine out, Sky2Pix in, int64_t nxo, int64_t nyo,
+                                                      int32_t* __restrict__ xi0, double* __restrict__ xfx,
+                                                      int32_t* __restrict__ yj0, double* __restrict__ yfy) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nxo + nyo; k += stride) {
+        if (k < nxo) {
+            double a = p2s_ra(out, (double)(k + 1));
+            split_cell(s2p_x(in, a), &xi0[k], &xfx[k]);
+        } else {
+            int64_t j = k - nxo;
+            double d = p2s_dec(out, (double)(j + 1));
+            split_cell(s2p_y(in, d), &yj0[j], &yfy[j]);
+        }
+    }
+}
+
+struct ReprojParams {
+    const double* src;     // (nx, src_nrows, nc)
+    double* dst;           // (nxo, dst_nrows, nc)
+    const int32_t* xi0; const double* xfx;   // nxo entries
+    const int32_t* yj0; const double* yfy;   // nyo entries (absolute output row)
+    int64_t nx, ny, src_row0, src_nrows;
+    int64_t nxo, dst_row0, dst_nrows;
+    int64_t r0, nr;        // output rows handled by this launch, relative to the dst window
+    int32_t nc, periodic;
+    // staged kernel only
+    int32_t rh;            // output rows per tile
+    int32_t seg;           // LDS slot length in doubles (even)
+    int32_t dxpos;         // source column increases with output column
+    int32_t ntx, nty;      // tiles along RA / DEC
+    int64_t ntiles, tiles_per_xcd;
+};
+
+// ---- generic direct-gather kernel: one lane per output pixel pair, 4 taps from global memory each.
+//      Used when a tile's source footprint does not fit the LDS ring (large down-scaling) and as the
+//      cross-check variant.
+__global__ __launch_bounds__(256) void k_reproject_gather(ReprojParams p) {
+    const int64_t npair = (p.nxo + 1) / 2;
+    const int64_t total = npair * p.nr;
+    const int c = blockIdx.y;
+    SrcView m{p.src + (int64_t)c * p.nx * p.src_nrows, p.nx, p.ny, p.src_row0, p.src_nrows, p.periodic};
+    double* dplane = p.dst + (int64_t)c * p.nxo * p.dst_nrows;
+    const bool vec = ((p.nxo & 1) == 0) && (((uintptr_t)p.dst & 15) == 0);
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        int64_t rr = t / npair;
+        int64_t i = (t - rr * npair) * 2;
+        int64_t r = p.r0 + rr;
+        int64_t j0 = p.yj0[p.dst_row0 + r];
+        double fy = p.yfy[p.dst_row0 + r];
+        double v0 = bilerp_cells(m, p.xi0[i], p.xfx[i], j0, fy);
+        int64_t o = r * p.nxo + i;
+        if (i + 1 < p.nxo) {
+            double v1 = bilerp_cells(m, p.xi0[i + 1], p.xfx[i + 1], j0, fy);
+            if (vec) *reinterpret_cast<double2*>(dplane + o) = make_double2(v0, v1);
+            else { dplane[o] = v0; dplane[o + 1] = v1; }
+        } else {
+            dplane[o] = v0;
+        }
+    }
+}
+
+// ---- staged kernel: ONE WAVEFRONT PER OUTPUT TILE.
+//
+// A tile is TW = 128*PAIRS output columns x rh output rows of one component plane.  The wave marches
+// down the tile's rows.  The two source rows an output row needs (j0, j0+1) live in a 4-slot LDS ring
+// (slot = row & 3, tagged with the row id), each slot holding the contiguous source-column segment the
+// tile's columns touch, loaded with 16 B/lane coalesced reads; the RA seam of a full-sky map is
+// resolved while staging (segment column u -> u mod nx), so the interpolation itself never sees it.
+// Rows for output row r+1 are prefetched into registers while row r is computed and stored.
+// Output is written with 16 B/lane coalesced stores (lane = 2 adjacent RA pixels per PAIR).
+//
+// Tiles whose columns do not fit the slot (the rewind discontinuity of a partial-sky source falling
+// inside the tile) fall back, wave-uniformly, to direct taps.
+#define PXL_NS 4
+#define PXL_MAXCH 5     // 16-B chunks of 64 lanes per slot: slot <= 5*128 doubles
+
+template <bool VEC>
+__device__ inline void load_row_regs(const ReprojParams& p, const double* plane, int64_t j, int64_t cbase0,
+                                     int lane, double2 (&regs)[PXL_MAXCH]) {
+    // j: 1-based absolute source row (any integer).  Rows outside the map / resident window read as 0.
+    int64_t jr = j - 1 - p.src_row0;
+    const bool row_ok = (j >= 1) && (j <= p.ny) && (jr >= 0) && (jr < p.src_nrows);
+    const double* rowp = plane + (row_ok ? jr : 0) * p.nx;
+#pragma unroll
+    for (int ch = 0; ch < PXL_MAXCH; ++ch) {
+        int k = ch * 128 + 2 * lane;
+        double2 v = make_double2(0.0, 0.0);
+        if (k < p.seg && row_ok) {
+            int64_t u = cbase0 + k;                   // 0-based unwrapped column of the chunk's first element
+            if (VEC) {
+                // nx even and u even: the pair never straddles the seam or the map edge
+                bool ok = true;
+                if (p.periodic) { u %= p.nx; if (u < 0) u += p.nx; }
+                else ok = (u >= 0) && (u < p.nx);
+                if (ok) v = *reinterpret_cast<const double2*>(rowp + u);
+            } else {
+                int64_t u0 = u, u1 = u + 1;
+                bool ok0 = true, ok1 = true;
+                if (p.periodic) {
+                    u0 %= p.nx; if (u0 < 0) u0 += p.nx;
+                    u1 %= p.nx; if (u1 < 0) u1 += p.nx;
+                } else {
+                    ok0 = (u0 >= 0) && (u0 < p.nx);
+                    ok1 = (u1 >= 0) && (u1 < p.nx);
+                }
+                if (ok0) v.x = rowp[u0];
+                if (ok1) v.y = rowp[u1];
+            }
+        }
+        regs[ch] = v;
+    }
+}
+
+__device__ inline void store_row_lds(const ReprojParams& p, double* slot, int lane, const double2 (&regs)[PXL_MAXCH]) {
+#pragma unroll
+    for (int ch = 0; ch < PXL_MAXCH; ++ch) {
+        int k = ch * 128 + 2 * lane;
+        if (k < p.seg) *reinterpret_cast<double2*>(slot + k) = regs[ch];
+    }
+}
+
+template <int PAIRS, bool VEC>
+__global__ __launch_bounds__(64) void k_reproject_staged(ReprojParams p) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // PXL_NS * seg doubles
+    const int lane = threadIdx.x;
+    constexpr int TW = 128 * PAIRS;
+
+    // XCD-aware decode: hardware deals blocks round-robin over the 8 XCDs (b % 8); give each XCD a
+    // contiguous run of tiles so RA-neighbouring tiles (which share 128-B lines at their edges and the
+    // same source rows) hit the same L2.  Placement only affects speed, never correctness.
+    const int64_t b = blockIdx.x;
+    const int64_t t = (b & 7) * p.tiles_per_xcd + (b >> 3);
+    if (t >= p.ntiles) return;
+    const int tx = (int)(t % p.ntx);
+    const int64_t trest = t / p.ntx;
+    const int ty = (int)(trest % p.nty);
+    const int c = (int)(trest / p.nty);
+
+    const double* splane = p.src + (int64_t)c * p.nx * p.src_nrows;
+    double* dplane = p.dst + (int64_t)c * p.nxo * p.dst_nrows;
+
+    const int64_t c0 = (int64_t)tx * TW;                       // first output column of the tile
+    const int64_t clast = (c0 + TW < p.nxo ? c0 + TW : p.nxo) - 1;
+    const int64_t rb = p.r0 + (int64_t)ty * p.rh;              // rows relative to the dst window
+    const int64_t re = (rb + p.rh < p.r0 + p.nr) ? rb + p.rh : p.r0 + p.nr;
+
+    // ---- per-lane column setup
+    const int64_t a = p.dxpos ? p.xi0[c0] : p.xi0[clast];      // 1-based source cell of the tile's low end
+    const int64_t ua = a - 1;
+    const int64_t cbase0 = ua & ~(int64_t)1;                   // even 0-based column at slot index 0
+    int dloc[PAIRS][2];
+    double fx[PAIRS][2];
+    bool act[PAIRS][2];
+    bool fits = true;
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            int64_t col = c0 + q * 128 + 2 * lane + e;
+            act[q][e] = col < p.nxo;
+            int64_t i0 = act[q][e] ? p.xi0[col] : a;
+            fx[q][e] = act[q][e] ? p.xfx[col] : 0.0;
+            int64_t d = i0 - a;
+            if (p.periodic) { d %= p.nx; if (d < 0) d += p.nx; }
+            d += ua - cbase0;
+            if (d < 0 || d + 1 >= p.seg) fits = false;
+            dloc[q][e] = (int)d;
+        }
+    }
+    const bool vec_store = ((p.nxo & 1) == 0) && (((uintptr_t)p.dst & 15) == 0);
+
+    if (!__all(fits)) {
+        // wave-uniform fallback: direct taps for this tile
+        SrcView m{splane, p.nx, p.ny, p.src_row0, p.src_nrows, p.periodic};
+        for (int64_t r = rb; r < re; ++r) {
+            int64_t j0 = p.yj0[p.dst_row0 + r];
+            double fy = p.yfy[p.dst_row0 + r];
+#pragma unroll
+            for (int q = 0; q < PAIRS; ++q)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    int64_t col = c0 + q * 128 + 2 * lane + e;
+                    if (act[q][e]) dplane[r * p.nxo + col] = bilerp_cells(m, p.xi0[col], fx[q][e], j0, fy);
+                }
+        }
+        return;
+    }
+
+    // ---- ring state (wave-uniform): tag of the source row held by each slot
+    int64_t tag0 = INT64_MIN, tag1 = INT64_MIN, tag2 = INT64_MIN, tag3 = INT64_MIN;
+    auto resident = [&](int64_t j) -> bool {
+        int s = (int)(j & 3);
+        int64_t tg = (s == 0) ? tag0 : (s == 1) ? tag1 : (s == 2) ? tag2 : tag3;
+        return tg == j;
+    };
+    auto settag = [&](int64_t j) {
+        int s = (int)(j & 3);
+        if (s == 0) tag0 = j; else if (s == 1) tag1 = j; else if (s == 2) tag2 = j; else tag3 = j;
+    };
+
+    double2 ra_[PXL_MAXCH], rb_[PXL_MAXCH];
+    {   // prologue: rows of the first output row
+        int64_t j0 = p.yj0[p.dst_row0 + rb];
+        load_row_regs<VEC>(p, splane, j0, cbase0, lane, ra_);
+        load_row_regs<VEC>(p, splane, j0 + 1, cbase0, lane, rb_);
+        store_row_lds(p, lds + (j0 & 3) * p.seg, lane, ra_);
+        store_row_lds(p, lds + ((j0 + 1) & 3) * p.seg, lane, rb_);
+        settag(j0); settag(j0 + 1);
+        __syncthreads();
+    }
+
+    for (int64_t r = rb; r < re; ++r) {
+        const int64_t j0 = p.yj0[p.dst_row0 + r];
+        const double fy = p.yfy[p.dst_row0 + r];
+
+        // prefetch the rows output row r+1 needs and the ring lacks (global -> registers)
+        bool needA = false, needB = false;
+        int64_t jn = 0;
+        if (r + 1 < re) {
+            jn = p.yj0[p.dst_row0 + r + 1];
+            needA = !resident(jn);
+            needB = !resident(jn + 1);
+            if (needA) load_row_regs<VEC>(p, splane, jn, cbase0, lane, ra_);
+            if (needB) load_row_regs<VEC>(p, splane, jn + 1, cbase0, lane, rb_);
+        }
+
+        // interpolate output row r from LDS
+        const double* T = lds + (j0 & 3) * p.seg;
+        const double* B = lds + ((j0 + 1) & 3) * p.seg;
+        const double wy = 1 - fy;
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) {
+            double v[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                int d = dloc[q][e];
+                double wx = 1 - fx[q][e];
+                double top = wx * T[d] + fx[q][e] * T[d + 1];
+                double bot = wx * B[d] + fx[q][e] * B[d + 1];
+                v[e] = wy * top + fy * bot;
+            }
+            int64_t col = c0 + q * 128 + 2 * lane;
+            double* o = dplane + r * p.nxo + col;
+            if (vec_store) { if (act[q][0]) *reinterpret_cast<double2*>(o) = make_double2(v[0], v[1]); }
+            else { if (act[q][0]) o[0] = v[0]; if (act[q][1]) o[1] = v[1]; }
+        }
+
+        if (needA || needB) {
+            __syncthreads();                       // every lane is done reading the slots being replaced
+            if (needA) { store_row_lds(p, lds + (jn & 3) * p.seg, lane, ra_); settag(jn); }
+            if (needB) { store_row_lds(p, lds + ((jn + 1) & 3) * p.seg, lane, rb_); settag(jn + 1); }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- scattered sample: one lane per point, fused sky2pix!(safe=true) + 2x2 gather.
+__global__ __launch_bounds__(256) void k_sample_bilinear(Sky2Pix s, const double* __restrict__ src, int64_t nx,
+                                                         int64_t ny, int32_t nc, int64_t row0, int64_t nrows,
+                                                         int periodic, int64_t n, const double2* __restrict__ sky,
+                                                         double* __restrict__ out) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        double2 ad = sky[k];
+        double x = s2p_x(s, ad.x), y = s2p_y(s, ad.y);
+        bool fin = isfinite(x) && isfinite(y);
+        int32_t i0, j0; double fx, fy;
+        split_cell(x, &i0, &fx);
+        split_cell(y, &j0, &fy);
+        for (int c = 0; c < nc; ++c) {
+            SrcView m{src + (int64_t)c * nx * nrows, nx, ny, row0, nrows, periodic};
+            double v = bilerp_cells(m, i0, fx, j0, fy);
+            out[(int64_t)c * n + k] = fin ? v : __builtin_nan("");
+        }
+    }
+}
+
+// ---- synthetic data (benchmark plumbing): splitmix64 counter RNG
+__device__ inline uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ inline double u01(uint64_t bits) { return (double)(bits >> 11) * (1.0 / 9007199254740992.0); }
+
+__global__ __launch_bounds__(256) void k_fill_random(double* __restrict__ dst, int64_t n, uint64_t seed,
+                                                     uint64_t offset, int kind) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        uint64_t ctr = (uint64_t)k + offset;
+        uint64_t h1 = splitmix64(seed ^ splitmix64(2 * ctr));
+        double u1 = u01(h1);
+        if (kind == 1) { dst[k] = u1; continue; }
+        uint64_t h2 = splitmix64(seed ^ splitmix64(2 * ctr + 1));
+        double u2 = u01(h2);
+        dst[k] = sqrt(-2.0 * log(1.0 - u1)) * cos(PXL_TWOPI_D * u2);   // Box-Muller
+    }
+}
+__global__ __launch_bounds__(256) void k_fill_sphere(double2* __restrict__ sky, int64_t n, uint64_t seed,
+                                                     uint64_t offset) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        uint64_t ctr = (uint64_t)k + offset;
+        double u1 = u01(splitmix64(seed ^ splitmix64(2 * ctr)));
+        double u2 = u01(splitmix64(seed ^ splitmix64(2 * ctr + 1)));
+        sky[k] = make_double2(PXL_TWOPI_D * u1 - PXL_PI_D, asin(2.0 * u2 - 1.0));
+    }
+}
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+struct pxl_reproject_plan {
+    pxl_car_wcs win, wout;
+    int64_t nx, ny, nc, src_row0, src_nrows;
+    int64_t nxo, nyo, dst_row0, dst_nrows;
+    int periodic;
+    int device;
+    // device tables
+    int32_t* xi0; double* xfx; int32_t* yj0; double* yfy;
+    void* table_mem;
+    // host copy of the row table (cells only), same arithmetic as the device
+    int32_t* h_yj0;
+    // launch configuration
+    int variant;       // 0 auto, 1 gather, 2 staged
+    int pairs;         // 1 or 2
+    int rh;
+    int seg;
+    int dxpos;
+    bool staged_ok;
+    bool vec_load;
+    bool tables_built;
+};
+
+extern "C" {
+
+int pxl_version(void) { return PXL_VERSION; }
+
+size_t pxl_last_error(char* buf, size_t n) {
+    size_t len = strlen(g_err);
+    if (buf && n) {
+        size_t m = len < n - 1 ? len : n - 1;
+        memcpy(buf, g_err, m);
+        buf[m] = 0;
+    }
+    return len;
+}
+
+int pxl_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(PXL_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+int pxl_pix2sky_car_f64(const pxl_car_wcs* wcs, int64_t n, const double* pix, double* sky, int wrap_mode,
+                        void* stream) {
+    if (!wcs_ok(wcs)) return fail(PXL_EINVAL, "pix2sky: invalid WCS");
+    if (n < 0 || (n > 0 && (!pix || !sky))) return fail(PXL_EINVAL, "pix2sky: null buffer or negative n");
+    if (wrap_mode < PXL_WRAP_NONE || wrap_mode > PXL_WRAP_UNWIND) return fail(PXL_EINVAL, "pix2sky: bad wrap_mode %d", wrap_mode);
+    if ((((uintptr_t)pix | (uintptr_t)sky) & 15) != 0) return fail(PXL_EINVAL, "pix2sky: 2xN buffers must be 16-byte aligned");
+    if (n == 0) return PXL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    CarAffine c = car_affine(*wcs);
+    hipLaunchKernelGGL(k_pix2sky_pairs, dim3(stream_grid(n, 256)), dim3(256), 0, st, c, n,
+                       (const double2*)pix, (double2*)sky, wrap_mode == PXL_WRAP_REWIND ? 1 : 0);
+    int rc = check_launch("k_pix2sky_pairs");
+    if (rc) return rc;
+    if (wrap_mode == PXL_WRAP_UNWIND) {
+        hipLaunchKernelGGL(k_unwind_rows, dim3(2), dim3(64), 0, st, n, sky, PXL_TWOPI_D, 0.0);
+        rc = check_launch("k_unwind_rows");
+    }
+    return rc;
+}
+
+int pxl_pix2sky_car_soa_f64(const pxl_car_wcs* wcs, int64_t n, const double* ipix, const double* jpix,
+                            double* ra, double* dec, int safe, void* stream) {
+    if (!wcs_ok(wcs)) return fail(PXL_EINVAL, "pix2sky_soa: invalid WCS");
+    if (n < 0 || (n > 0 && (!ipix || !jpix || !ra || !dec))) return fail(PXL_EINVAL, "pix2sky_soa: null buffer or negative n");
+    if (n == 0) return PXL_OK;
+    hipLaunchKernelGGL(k_pix2sky_soa, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       car_affine(*wcs), n, ipix, jpix, ra, dec, safe ? 1 : 0);
+    return check_launch("k_pix2sky_soa");
+}
+
+int pxl_sky2pix_car_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64_t n, const double* sky,
+                        double* pix, int safe, int form, void* stream) {
+    if (!wcs_ok(wcs) || !shape) return fail(PXL_EINVAL, "sky2pix: invalid WCS/shape");
+    if (n < 0 || (n > 0 && (!pix || !sky))) return fail(PXL_EINVAL, "sky2pix: null buffer or negative n");
+    if (form < 0 || form > 2) return fail(PXL_EINVAL, "sky2pix: bad form %d", form);
+    if ((((uintptr_t)pix | (uintptr_t)sky) & 15) != 0) return fail(PXL_EINVAL, "sky2pix: 2xN buffers must be 16-byte aligned");
+    if (n == 0) return PXL_OK;
+    Sky2Pix s = sky2pix_setup(*wcs, shape[0], shape[1], safe ? 1 : 0, form);
+    hipLaunchKernelGGL(k_sky2pix_pairs, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, s, n,
+                       (const double2*)sky, (double2*)pix);
+    return check_launch("k_sky2pix_pairs");
+}
+
+int pxl_sky2pix_car_soa_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64_t n, const double* ra,
+                            const double* dec, double* ipix, double* jpix, int safe, int form, void* stream) {
+    if (!wcs_ok(wcs) || !shape) return fail(PXL_EINVAL, "sky2pix_soa: invalid WCS/shape");
+    if (n < 0 || (n > 0 && (!ipix || !jpix || !ra || !dec))) return fail(PXL_EINVAL, "sky2pix_soa: null buffer or negative n");
+    if (form < 0 || form > 2) return fail(PXL_EINVAL, "sky2pix_soa: bad form %d", form);
+    if (n == 0) return PXL_OK;
+    Sky2Pix s = sky2pix_setup(*wcs, shape[0], shape[1], safe ? 1 : 0, form);
+    hipLaunchKernelGGL(k_sky2pix_soa, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, s, n, ra,
+                       dec, ipix, jpix);
+    return check_launch("k_sky2pix_soa");
+}
+
+static int check_rows(const char* who, const int64_t shape[2], int64_t row0, int64_t nrows) {
+    if (!shape || shape[0] < 1 || shape[1] < 1) return fail(PXL_EINVAL, "%s: bad shape", who);
+    if (row0 < 0 || nrows < 0 || row0 + nrows > shape[1])
+        return fail(PXL_EINVAL, "%s: rows [%lld, %lld) outside the map (ny=%lld)", who, (long long)row0,
+                    (long long)(row0 + nrows), (long long)shape[1]);
+    return PXL_OK;
+}
+
+int pxl_posmap_car_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64_t row0, int64_t nrows,
+                       double* ra, double* dec, int safe, void* stream) {
+    if (!wcs_ok(wcs)) return fail(PXL_EINVAL, "posmap: invalid WCS");
+    int rc = check_rows("posmap", shape, row0, nrows);
+    if (rc) return rc;
+    if (nrows == 0) return PXL_OK;
+    if (!ra || !dec) return fail(PXL_EINVAL, "posmap: null output");
+    int64_t work = ((shape[0] + 1) / 2) * nrows;
+    hipLaunchKernelGGL(k_posmap_car, dim3(stream_grid(work, 256)), dim3(256), 0, (hipStream_t)stream,
+                       car_affine(*wcs), shape[0], row0, nrows, ra, dec, safe ? 1 : 0);
+    return check_launch("k_posmap_car");
+}
+
+int pxl_pixareamap_car_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64_t row0, int64_t nrows,
+                           double* area, void* stream) {
+    if (!wcs_ok(wcs)) return fail(PXL_EINVAL, "pixareamap: invalid WCS");
+    int rc = check_rows("pixareamap", shape, row0, nrows);
+    if (rc) return rc;
+    if (nrows == 0) return PXL_OK;
+    if (!area) return fail(PXL_EINVAL, "pixareamap: null output");
+    int64_t work = ((shape[0] + 1) / 2) * nrows;
+    hipLaunchKernelGGL(k_pixareamap_car, dim3(stream_grid(work, 256)), dim3(256), 0, (hipStream_t)stream,
+                       car_affine(*wcs), shape[0], row0, nrows, area);
+    return check_launch("k_pixareamap_car");
+}
+
+int pxl_sky2pix_tan_f64(const pxl_car_wcs* wcs, int64_t n, const double* ra, const double* dec, double* ipix,
+                        double* jpix, void* stream) {
+    if (!wcs_ok(wcs)) return fail(PXL_EINVAL, "sky2pix_tan: invalid WCS");
+    if (n < 0 || (n > 0 && (!ipix || !jpix || !ra || !dec))) return fail(PXL_EINVAL, "sky2pix_tan: null buffer or negative n");
+    if (n == 0) return PXL_OK;
+    hipLaunchKernelGGL(k_sky2pix_tan, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       tan_setup(*wcs), n, ra, dec, ipix, jpix);
+    return check_launch("k_sky2pix_tan");
+}
+
+int pxl_pix2sky_tan_f64(const pxl_car_wcs* wcs, int64_t n, const double* ipix, const double* jpix, double* ra,
+                        double* dec, void* stream) {
+    if (!wcs_ok(wcs)) return fail(PXL_EINVAL, "pix2sky_tan: invalid WCS");
+    if (n < 0 || (n > 0 && (!ipix || !jpix || !ra || !dec))) return fail(PXL_EINVAL, "pix2sky_tan: null buffer or negative n");
+    if (n == 0) return PXL_OK;
+    hipLaunchKernelGGL(k_pix2sky_tan, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       tan_setup(*wcs), n, ipix, jpix, ra, dec);
+    return check_launch("k_pix2sky_tan");
+}
+
+int pxl_posmap_tan_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64_t row0, int64_t nrows, double* ra,
+                       double* dec, void* stream) {
+    if (!wcs_ok(wcs)) return fail(PXL_EINVAL, "posmap_tan: invalid WCS");
+    int rc = check_rows("posmap_tan", shape, row0, nrows);
+    if (rc) return rc;
+    if (nrows == 0) return PXL_OK;
+    if (!ra || !dec) return fail(PXL_EINVAL, "posmap_tan: null output");
+    hipLaunchKernelGGL(k_posmap_tan, dim3(stream_grid(shape[0] * nrows, 256)), dim3(256), 0,
+                       (hipStream_t)stream, tan_setup(*wcs), shape[0], row0, nrows, ra, dec);
+    return check_launch("k_posmap_tan");
+}
+
+// ---- reprojection plan -------------------------------------------------------------------------
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+int pxl_reproject_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], int64_t src_row0,
+                              int64_t src_nrows, const pxl_car_wcs* wcs_out, const int64_t shape_out[2],
+                              int64_t dst_row0, int64_t dst_nrows, pxl_reproject_plan** out) {
+    if (!out) return fail(PXL_EINVAL, "plan_create: null plan pointer");
+    *out = nullptr;
+    if (!wcs_ok(wcs_in) || !wcs_ok(wcs_out)) return fail(PXL_EINVAL, "plan_create: invalid WCS");
+    if (!shape_in || !shape_out) return fail(PXL_EINVAL, "plan_create: null shape");
+    if (shape_in[0] < 1 || shape_in[1] < 1 || shape_in[2] < 1 || shape_out[0] < 1 || shape_out[1] < 1)
+        return fail(PXL_EINVAL, "plan_create: shapes must be positive");
+    if (shape_in[0] > 1000000000 || shape_in[1] > 1000000000 || shape_out[0] > 1000000000 || shape_out[1] > 1000000000)
+        return fail(PXL_EINVAL, "plan_create: axis longer than 1e9 pixels");
+    if (src_row0 < 0 || src_nrows < 0 || src_row0 + src_nrows > shape_in[1])
+        return fail(PXL_EINVAL, "plan_create: source window outside the map");
+    if (dst_row0 < 0 || dst_nrows < 0 || dst_row0 + dst_nrows > shape_out[1])
+        return fail(PXL_EINVAL, "plan_create: destination window outside the map");
+
+    pxl_reproject_plan* pl = new (std::nothrow) pxl_reproject_plan();
+    if (!pl) return fail(PXL_ENOMEM, "plan_create: host allocation failed");
+    pl->win = *wcs_in; pl->wout = *wcs_out;
+    pl->nx = shape_in[0]; pl->ny = shape_in[1]; pl->nc = shape_in[2];
+    pl->src_row0 = src_row0; pl->src_nrows = src_nrows;
+    pl->nxo = shape_out[0]; pl->nyo = shape_out[1];
+    pl->dst_row0 = dst_row0; pl->dst_nrows = dst_nrows;
+    // full-circle test: same 1e-8 threshold as enmap_geom.jl:55
+    pl->periodic = fabs((double)pl->nx * fabs(wcs_in->cdelt[0] * wcs_in->unit) - PXL_TWOPI_D) < 1e-8;
+    pl->tables_built = false;
+    pl->variant = env_int("PXL_REPROJECT_VARIANT", 0);
+
+    hipError_t e = hipGetDevice(&pl->device);
+    if (e != hipSuccess) { delete pl; return fail(PXL_ENODEV, "hipGetDevice: %s", hipGetErrorString(e)); }
+
+    // tables: [xfx nxo doubles][yfy nyo doubles][xi0 nxo int32][yj0 nyo int32], 16-B aligned pieces
+    size_t nxo = (size_t)pl->nxo, nyo = (size_t)pl->nyo;
+    size_t off_xfx = 0;
+    size_t off_yfy = off_xfx + ((nxo * 8 + 15) & ~(size_t)15);
+    size_t off_xi0 = off_yfy + ((nyo * 8 + 15) & ~(size_t)15);
+    size_t off_yj0 = off_xi0 + ((nxo * 4 + 15) & ~(size_t)15);
+    size_t total = off_yj0 + ((nyo * 4 + 15) & ~(size_t)15);
+    e = hipMalloc(&pl->table_mem, total);
+    if (e != hipSuccess) { delete pl; return fail(PXL_ENOMEM, "plan_create: hipMalloc(%zu): %s", total, hipGetErrorString(e)); }
+    char* base = (char*)pl->table_mem;
+    pl->xfx = (double*)(base + off_xfx); pl->yfy = (double*)(base + off_yfy);
+    pl->xi0 = (int32_t*)(base + off_xi0); pl->yj0 = (int32_t*)(base + off_yj0);
+
+    // host copy of the row cells (identical arithmetic: fmod/div/floor are exact or correctly rounded)
+    pl->h_yj0 = new (std::nothrow) int32_t[nyo];
+    if (!pl->h_yj0) { (void)hipFree(pl->table_mem); delete pl; return fail(PXL_ENOMEM, "plan_create: host allocation failed"); }
+    CarAffine co = car_affine(pl->wout);
+    Sky2Pix si = sky2pix_setup(pl->win, pl->nx, pl->ny, 1, PXL_FORM_DIV);
+    for (int64_t j = 0; j < pl->nyo; ++j) {
+        double fr;
+        split_cell(s2p_y(si, p2s_dec(co, (double)(j + 1))), &pl->h_yj0[j], &fr);
+    }
+
+    // ---- choose the launch configuration from the RA scale (source columns per output column)
+    double sx = fabs((pl->wout.cdelt[0] * pl->wout.unit) / (pl->win.cdelt[0] * pl->win.unit));
+    pl->dxpos = ((pl->wout.cdelt[0] * pl->wout.unit) / (pl->win.cdelt[0] * pl->win.unit)) > 0 ? 1 : 0;
+    pl->pairs = env_int("PXL_REPROJECT_PAIRS", 2);
+    if (pl->pairs != 1 && pl->pairs != 2) pl->pairs = 2;
+    pl->rh = env_int("PXL_REPROJECT_RH", 64);
+    if (pl->rh < 1) pl->rh = 1;
+    const int max_seg = PXL_MAXCH * 128;
+    auto seg_for = [&](int pairs) -> int64_t {
+        // footprint of TW columns: ceil(TW*sx) cells + 2 (tap +1, rounding) + 1 (even alignment) + 2 slack
+        double span = ceil((double)(128 * pairs) * sx) + 5.0;
+        int64_t s = (int64_t)span;
+        return (s + 1) & ~(int64_t)1;
+    };
+    int64_t seg = seg_for(pl->pairs);
+    if (seg > max_seg && pl->pairs == 2) { pl->pairs = 1; seg = seg_for(1); }
+    pl->staged_ok = (seg <= max_seg) && !(pl->periodic && seg > pl->nx);   // slot never laps the ring of pixels
+    pl->seg = (int)(seg <= max_seg ? seg : max_seg);
+    pl->vec_load = (pl->nx % 2 == 0);
+    *out = pl;
+    return PXL_OK;
+}
+
+int pxl_reproject_plan_set_variant(pxl_reproject_plan* pl, int variant) {
+    if (!pl || variant < 0 || variant > 2) return fail(PXL_EINVAL, "set_variant: bad argument");
+    pl->variant = variant;
+    return PXL_OK;
+}
+
+int pxl_reproject_plan_destroy(pxl_reproject_plan* pl) {
+    if (!pl) return PXL_OK;
+    if (pl->table_mem) (void)hipFree(pl->table_mem);
+    delete[] pl->h_yj0;
+    delete pl;
+    return PXL_OK;
+}
+
+int pxl_reproject_build_tables(pxl_reproject_plan* pl, void* stream) {
+    if (!pl) return fail(PXL_EINVAL, "build_tables: null plan");
+    CarAffine co = car_affine(pl->wout);
+    Sky2Pix si = sky2pix_setup(pl->win, pl->nx, pl->ny, 1, PXL_FORM_DIV);
+    hipLaunchKernelGGL(k_build_tables, dim3(stream_grid(pl->nxo + pl->nyo, 256)), dim3(256), 0,
+                       (hipStream_t)stream, co, si, pl->nxo, pl->nyo, pl->xi0, pl->xfx, pl->yj0, pl->yfy);
+    int rc = check_launch("k_build_tables");
+    if (rc == PXL_OK) pl->tables_built = true;
+    return rc;
+}
+
+int pxl_reproject_execute_rows(pxl_reproject_plan* pl, const double* src, double* dst, int64_t r0, int64_t nr,
+                               void* stream) {
+    if (!pl) return fail(PXL_EINVAL, "execute: null plan");
+    if (r0 < 0 || nr < 0 || r0 + nr > pl->dst_nrows) return fail(PXL_EINVAL, "execute: rows outside the dst window");
+    if (nr == 0) return PXL_OK;
+    if (!dst || (!src && pl->src_nrows > 0)) return fail(PXL_EINVAL, "execute: null src/dst");
+    if (!pl->tables_built) return fail(PXL_EINVAL, "execute_rows: tables not built");
+    hipStream_t st = (hipStream_t)stream;
+
+    ReprojParams p;
+    memset(&p, 0, sizeof(p));
+    p.src = src; p.dst = dst;
+    p.xi0 = pl->xi0; p.xfx = pl->xfx; p.yj0 = pl->yj0; p.yfy = pl->yfy;
+    p.nx = pl->nx; p.ny = pl->ny; p.src_row0 = pl->src_row0; p.src_nrows = pl->src_nrows;
+    p.nxo = pl->nxo; p.dst_row0 = pl->dst_row0; p.dst_nrows = pl->dst_nrows;
+    p.r0 = r0; p.nr = nr; p.nc = (int32_t)pl->nc; p.periodic = pl->periodic;
+
+    bool staged = pl->staged_ok;
+    if (pl->variant == 1) staged = false;
+    if (!staged) {
+        int64_t work = ((pl->nxo + 1) / 2) * nr;
+        hipLaunchKernelGGL(k_reproject_gather, dim3(stream_grid(work, 256), (unsigned)pl->nc), dim3(256), 0, st, p);
+        return check_launch("k_reproject_gather");
+    }
+
+    const int TW = 128 * pl->pairs;
+    p.rh = pl->rh; p.seg = pl->seg; p.dxpos = pl->dxpos;
+    p.ntx = (int32_t)((pl->nxo + TW - 1) / TW);
+    p.nty = (int32_t)((nr + pl->rh - 1) / pl->rh);
+    p.ntiles = (int64_t)p.ntx * p.nty * pl->nc;
+    p.tiles_per_xcd = (p.ntiles + 7) / 8;
+    int64_t nblocks = p.tiles_per_xcd * 8;
+    if (nblocks > 0x7fffffffLL) return fail(PXL_EINVAL, "execute: too many tiles (%lld)", (long long)nblocks);
+    size_t lds_bytes = (size_t)PXL_NS * (size_t)pl->seg * sizeof(double);
+    const bool vec = pl->vec_load && (((uintptr_t)src & 15) == 0);
+    dim3 grid((unsigned)nblocks), block(64);
+    if (pl->pairs == 2) {
+        if (vec) hipLaunchKernelGGL((k_reproject_staged<2, true>), grid, block, lds_bytes, st, p);
+        else     hipLaunchKernelGGL((k_reproject_staged<2, false>), grid, block, lds_bytes, st, p);
+    } else {
+        if (vec) hipLaunchKernelGGL((k_reproject_staged<1, true>), grid, block, lds_bytes, st, p);
+        else     hipLaunchKernelGGL((k_reproject_staged<1, false>), grid, block, lds_bytes, st, p);
+    }
+    return check_launch("k_reproject_staged");
+}
+
+int pxl_reproject_execute(pxl_reproject_plan* pl, const double* src, double* dst, void* stream) {
+    int rc = pxl_reproject_build_tables(pl, stream);
+    if (rc) return rc;
+    return pxl_reproject_execute_rows(pl, src, dst, 0, pl->dst_nrows, stream);
+}
+
+int pxl_reproject_plan_src_rows(const pxl_reproject_plan* pl, int64_t* lo, int64_t* hi) {
+    if (!pl || !lo || !hi) return fail(PXL_EINVAL, "plan_src_rows: null argument");
+    int64_t l = INT64_MAX, h = INT64_MIN;
+    for (int64_t r = 0; r < pl->dst_nrows; ++r) {
+        int64_t j0 = pl->h_yj0[pl->dst_row0 + r];
+        for (int64_t j = j0; j <= j0 + 1; ++j)
+            if (j >= 1 && j <= pl->ny) { if (j - 1 < l) l = j - 1; if (j > h) h = j; }
+    }
+    if (l > h) { l = 0; h = 0; }
+    *lo = l; *hi = h;
+    return PXL_OK;
+}
+
+int pxl_reproject_plan_rows_covered(const pxl_reproject_plan* pl, int64_t have_lo, int64_t have_hi, int64_t* lo,
+                                    int64_t* hi) {
+    if (!pl || !lo || !hi) return fail(PXL_EINVAL, "plan_rows_covered: null argument");
+    // longest run of output rows (relative) whose in-map taps j0, j0+1 all lie in [have_lo, have_hi)
+    int64_t best_lo = 0, best_hi = 0, cur_lo = -1;
+    for (int64_t r = 0; r <= pl->dst_nrows; ++r) {
+        bool ok = false;
+        if (r < pl->dst_nrows) {
+            int64_t j0 = pl->h_yj0[pl->dst_row0 + r];
+            ok = true;
+            for (int64_t j = j0; j <= j0 + 1; ++j)
+                if (j >= 1 && j <= pl->ny && !(j - 1 >= have_lo && j - 1 < have_hi)) ok = false;
+        }
+        if (ok) { if (cur_lo < 0) cur_lo = r; }
+        else if (cur_lo >= 0) {
+            if (r - cur_lo > best_hi - best_lo) { best_lo = cur_lo; best_hi = r; }
+            cur_lo = -1;
+        }
+    }
+    *lo = best_lo; *hi = best_hi;
+    return PXL_OK;
+}
+
+int pxl_reproject_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], const double* src,
+                                   const pxl_car_wcs* wcs_out, const int64_t shape_out[2], double* dst,
+                                   void* stream) {
+    if (!shape_in || !shape_out) return fail(PXL_EINVAL, "reproject: null shape");
+    pxl_reproject_plan* pl = nullptr;
+    int rc = pxl_reproject_plan_create(wcs_in, shape_in, 0, shape_in[1], wcs_out, shape_out, 0, shape_out[1], &pl);
+    if (rc) return rc;
+    rc = pxl_reproject_execute(pl, src, dst, stream);
+    if (rc == PXL_OK) {
+        hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        if (e != hipSuccess) rc = fail(PXL_EHIP, "reproject: %s", hipGetErrorString(e));
+    }
+    pxl_reproject_plan_destroy(pl);
+    return rc;
+}
+
+int pxl_sample_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], const double* src,
+                                int64_t src_row0, int64_t src_nrows, int64_t n, const double* sky, double* out,
+                                void* stream) {
+    if (!wcs_ok(wcs_in) || !shape_in) return fail(PXL_EINVAL, "sample: invalid WCS/shape");
+    if (shape_in[0] < 1 || shape_in[1] < 1 || shape_in[2] < 1) return fail(PXL_EINVAL, "sample: shapes must be positive");
+    if (src_row0 < 0 || src_nrows < 0 || src_row0 + src_nrows > shape_in[1])
+        return fail(PXL_EINVAL, "sample: source window outside the map");
+    if (n < 0 || (n > 0 && (!sky || !out || (!src && src_nrows > 0)))) return fail(PXL_EINVAL, "sample: null buffer or negative n");
+    if (((uintptr_t)sky & 15) != 0) return fail(PXL_EINVAL, "sample: 2xN buffer must be 16-byte aligned");
+    if (n == 0) return PXL_OK;
+    Sky2Pix s = sky2pix_setup(*wcs_in, shape_in[0], shape_in[1], 1, PXL_FORM_RECIP);
+    int periodic = fabs((double)shape_in[0] * fabs(wcs_in->cdelt[0] * wcs_in->unit) - PXL_TWOPI_D) < 1e-8;
+    hipLaunchKernelGGL(k_sample_bilinear, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, s, src,
+                       shape_in[0], shape_in[1], (int32_t)shape_in[2], src_row0, src_nrows, periodic, n,
+                       (const double2*)sky, out);
+    return check_launch("k_sample_bilinear");
+}
+
+int pxl_fill_random_f64(double* dst, int64_t n, uint64_t seed, uint64_t offset, int kind, void* stream) {
+    if (n < 0 || (n > 0 && !dst)) return fail(PXL_EINVAL, "fill_random: null buffer or negative n");
+    if (n == 0) return PXL_OK;
+    hipLaunchKernelGGL(k_fill_random, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, dst, n, seed,
+                       offset, kind);
+    return check_launch("k_fill_random");
+}
+
+int pxl_fill_sphere_points_f64(double* sky, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+    if (n < 0 || (n > 0 && !sky)) return fail(PXL_EINVAL, "fill_sphere: null buffer or negative n");
+    if (((uintptr_t)sky & 15) != 0) return fail(PXL_EINVAL, "fill_sphere: 2xN buffer must be 16-byte aligned");
+    if (n == 0) return PXL_OK;
+    hipLaunchKernelGGL(k_fill_sphere, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, (double2*)sky,
+                       n, seed, offset);
+    return check_launch("k_fill_sphere");
+}
+
+}  // extern "C"

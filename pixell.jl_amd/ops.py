@@ -1,0 +1,374 @@
+"""Device operators: the reference's batched evaluators and the reprojection, through the C ABI.
+
+Names, argument meaning and `safe` keyword follow /root/reference/src/projections/car_proj.jl and
+src/enmap_ops.jl.  Dispatch mirrors the reference's methods:
+
+    pix2sky(m, pix2xN)            car_proj.jl:118-122   device, 2xN batch == torch tensor of shape (N, 2)
+    pix2sky(m, ivec, jvec)        car_proj.jl:141-152   device, two N-vectors (broadcast form)
+    pix2sky(m, i, j)              car_proj.jl:141-152   host scalar
+    pix2sky(m, [i, j])            car_proj.jl:155-162   host scalar, length-2 vector
+    sky2pix(m, sky2xN)            car_proj.jl:196-200   device
+    sky2pix(m, ravec, decvec)     car_proj.jl:235-252   device
+    sky2pix(m, ra, dec)           car_proj.jl:220-234   host scalar
+    sky2pix(m, [ra, dec])         car_proj.jl:255-259   host scalar
+
+`m` is an Enmap or a (shape, wcs) pair (enmap_ops.jl:60-66).  Every device path calls libpixell_hip.so;
+nothing here computes on the CPU in its place.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import FORM_DIV, FORM_RECIP, FORM_RECIP_AV, WRAP_NONE, WRAP_REWIND, WRAP_UNWIND
+from .enmap import Enmap, _geom
+from .wcs import (AbstractCARWCS, Gnomonic, pix2sky_scalar, pix2sky_tan_scalar, sky2pix_scalar,
+                  sky2pix_tan_scalar)
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _dev_f64(t: torch.Tensor, what: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch tensor" % what)
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU: the MI355X path has no CPU fallback "
+                           "(CPU arrays stay with the reference implementation)" % what)
+    if t.dtype != torch.float64:
+        raise TypeError("%s must be float64" % what)
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % what)
+    return t
+
+
+def _ptr(t: torch.Tensor):
+    return C.c_void_p(t.data_ptr())
+
+
+def _is_scalar(x):
+    return isinstance(x, (int, float))
+
+
+def _wcs_ref(wcs):
+    return C.byref(wcs.to_struct())
+
+
+def _shape2(shape):
+    return _lib.shape_arr((shape[0], shape[1]))
+
+
+# ---- pix2sky ------------------------------------------------------------------------------------
+
+def pix2sky_(m, pixcoords, skycoords, safe=True):
+    """pix2sky!(m, pixcoords, skycoords; safe) -- car_proj.jl:92-115.  Returns skycoords."""
+    shape, wcs = _geom(m)
+    _require_car(wcs)
+    pix = _dev_f64(pixcoords, "pixcoords")
+    sky = _dev_f64(skycoords, "skycoords")
+    if pix.dim() != 2 or pix.shape[1] != 2 or sky.shape != pix.shape:
+        raise ValueError("coordinate batches are (N, 2) tensors (Julia 2xN)")
+    with torch.cuda.device(pix.device):
+        _lib.check(_lib.load().pxl_pix2sky_car_f64(_wcs_ref(wcs), pix.shape[0], _ptr(pix), _ptr(sky),
+                                                   WRAP_UNWIND if safe else WRAP_NONE, _stream(pix)))
+    return sky
+
+
+def pix2sky(m, p1, p2=None, safe=True):
+    shape, wcs = _geom(m)
+    if isinstance(wcs, Gnomonic):
+        return _pix2sky_tan(shape, wcs, p1, p2)
+    _require_car(wcs)
+    if p2 is None:
+        if isinstance(p1, torch.Tensor):
+            return pix2sky_(m, p1, torch.empty_like(p1), safe=safe)
+        if len(p1) != 2:                       # @assert length(pixcoords) == 2, car_proj.jl:156
+            raise AssertionError("length(pixcoords) == 2")
+        # car_proj.jl:157: the inner scalar call does not forward `safe` (always rewinds);
+        # the unwind! that follows is a no-op on one point.
+        return list(pix2sky_scalar(shape, wcs, p1[0], p1[1], safe=True))
+    if _is_scalar(p1) and _is_scalar(p2):
+        return pix2sky_scalar(shape, wcs, p1, p2, safe=safe)
+    ip, jp = _dev_f64(p1, "ra_pixel"), _dev_f64(p2, "dec_pixel")
+    if ip.shape != jp.shape:
+        raise ValueError("ra_pixel and dec_pixel must have the same shape")
+    ra, dec = torch.empty_like(ip), torch.empty_like(jp)
+    with torch.cuda.device(ip.device):
+        _lib.check(_lib.load().pxl_pix2sky_car_soa_f64(_wcs_ref(wcs), ip.numel(), _ptr(ip), _ptr(jp), _ptr(ra),
+                                                       _ptr(dec), int(bool(safe)), _stream(ip)))
+    return ra, dec
+
+
+def pix2sky_rewind(m, pixcoords):
+    """2xN pix2sky with the per-element rewind of the scalar method (PXL_WRAP_REWIND)."""
+    shape, wcs = _geom(m)
+    pix = _dev_f64(pixcoords, "pixcoords")
+    sky = torch.empty_like(pix)
+    with torch.cuda.device(pix.device):
+        _lib.check(_lib.load().pxl_pix2sky_car_f64(_wcs_ref(wcs), pix.shape[0], _ptr(pix), _ptr(sky),
+                                                   WRAP_REWIND, _stream(pix)))
+    return sky
+
+
+# ---- sky2pix ------------------------------------------------------------------------------------
+
+def sky2pix_(m, skycoords, pixcoords, safe=True):
+    """sky2pix!(m, skycoords, pixcoords; safe) -- car_proj.jl:165-193.  Returns pixcoords."""
+    shape, wcs = _geom(m)
+    _require_car(wcs)
+    sky = _dev_f64(skycoords, "skycoords")
+    pix = _dev_f64(pixcoords, "pixcoords")
+    if sky.dim() != 2 or sky.shape[1] != 2 or sky.shape != pix.shape:
+        raise ValueError("coordinate batches are (N, 2) tensors (Julia 2xN)")
+    with torch.cuda.device(sky.device):
+        _lib.check(_lib.load().pxl_sky2pix_car_f64(_wcs_ref(wcs), _shape2(shape), sky.shape[0], _ptr(sky),
+                                                   _ptr(pix), int(bool(safe)), FORM_RECIP, _stream(sky)))
+    return pix
+
+
+def sky2pix(m, p1, p2=None, safe=True):
+    shape, wcs = _geom(m)
+    if isinstance(wcs, Gnomonic):
+        return _sky2pix_tan(shape, wcs, p1, p2)
+    _require_car(wcs)
+    if p2 is None:
+        if isinstance(p1, torch.Tensor):
+            return sky2pix_(m, p1, torch.empty_like(p1), safe=safe)
+        if len(p1) != 2:                       # car_proj.jl:256
+            raise AssertionError("length(skycoords) == 2")
+        return list(sky2pix_scalar(shape, wcs, p1[0], p1[1], safe=safe))
+    if _is_scalar(p1) and _is_scalar(p2):
+        return sky2pix_scalar(shape, wcs, p1, p2, safe=safe)
+    ra, dec = _dev_f64(p1, "ra"), _dev_f64(p2, "dec")
+    if ra.shape != dec.shape:
+        raise ValueError("ra and dec must have the same shape")
+    ip, jp = torch.empty_like(ra), torch.empty_like(dec)
+    with torch.cuda.device(ra.device):
+        _lib.check(_lib.load().pxl_sky2pix_car_soa_f64(_wcs_ref(wcs), _shape2(shape), ra.numel(), _ptr(ra),
+                                                       _ptr(dec), _ptr(ip), _ptr(jp), int(bool(safe)),
+                                                       FORM_RECIP_AV, _stream(ra)))
+    return ip, jp
+
+
+def sky2pix_broadcast(m, ra, dec, safe=True):
+    """sky2pix.(Ref(m), ra, dec): the scalar (division) form of car_proj.jl:220-234 over two vectors."""
+    shape, wcs = _geom(m)
+    ra, dec = _dev_f64(ra, "ra"), _dev_f64(dec, "dec")
+    ip, jp = torch.empty_like(ra), torch.empty_like(dec)
+    with torch.cuda.device(ra.device):
+        _lib.check(_lib.load().pxl_sky2pix_car_soa_f64(_wcs_ref(wcs), _shape2(shape), ra.numel(), _ptr(ra),
+                                                       _ptr(dec), _ptr(ip), _ptr(jp), int(bool(safe)),
+                                                       FORM_DIV, _stream(ra)))
+    return ip, jp
+
+
+def _require_car(wcs):
+    if not isinstance(wcs, AbstractCARWCS):
+        raise TypeError("only CAR WCS (CarClenshawCurtis / CarFejer1) and Gnomonic are accelerated; "
+                        "generic WCSTransform maps stay on the reference's wcslib path")
+
+
+# ---- Gnomonic -----------------------------------------------------------------------------------
+
+def _pix2sky_tan(shape, wcs, p1, p2):
+    if _is_scalar(p1) and _is_scalar(p2):
+        return pix2sky_tan_scalar(shape, wcs, p1, p2)
+    ip, jp = _dev_f64(p1, "ra_pixel"), _dev_f64(p2, "dec_pixel")
+    ra, dec = torch.empty_like(ip), torch.empty_like(jp)
+    with torch.cuda.device(ip.device):
+        _lib.check(_lib.load().pxl_pix2sky_tan_f64(_wcs_ref(wcs), ip.numel(), _ptr(ip), _ptr(jp), _ptr(ra),
+                                                   _ptr(dec), _stream(ip)))
+    return ra, dec
+
+
+def _sky2pix_tan(shape, wcs, p1, p2):
+    if _is_scalar(p1) and _is_scalar(p2):
+        return sky2pix_tan_scalar(shape, wcs, p1, p2)
+    ra, dec = _dev_f64(p1, "ra"), _dev_f64(p2, "dec")
+    ip, jp = torch.empty_like(ra), torch.empty_like(dec)
+    with torch.cuda.device(ra.device):
+        _lib.check(_lib.load().pxl_sky2pix_tan_f64(_wcs_ref(wcs), ra.numel(), _ptr(ra), _ptr(dec), _ptr(ip),
+                                                   _ptr(jp), _stream(ra)))
+    return ip, jp
+
+
+# ---- whole-map writers --------------------------------------------------------------------------
+
+def posmap(shape, wcs, device="cuda", row0=0, nrows=None, safe=True):
+    """posmap(shape, wcs) -- enmap_ops.jl:190-203: (ra_map, dec_map) Enmaps of the pixel centres.
+    row0/nrows select a declination strip (0-based rows) for sharded use."""
+    nx, ny = int(shape[0]), int(shape[1])
+    nrows = ny - row0 if nrows is None else nrows
+    dev = torch.device(device)
+    ra = torch.empty((nrows, nx), dtype=torch.float64, device=dev)
+    dec = torch.empty((nrows, nx), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        lib = _lib.load()
+        if isinstance(wcs, Gnomonic):
+            rc = lib.pxl_posmap_tan_f64(_wcs_ref(wcs), _shape2(shape), row0, nrows, _ptr(ra), _ptr(dec), _stream(ra))
+        else:
+            _require_car(wcs)
+            rc = lib.pxl_posmap_car_f64(_wcs_ref(wcs), _shape2(shape), row0, nrows, _ptr(ra), _ptr(dec),
+                                        int(bool(safe)), _stream(ra))
+        _lib.check(rc)
+    strip_wcs = wcs
+    if (row0, nrows) != (0, ny):
+        from .geometry import slice_geometry
+        _, strip_wcs = slice_geometry((nx, ny), wcs, None, (row0 + 1, row0 + nrows))
+    return Enmap(ra, strip_wcs), Enmap(dec, strip_wcs)
+
+
+def pixareamap_(pixareas: Enmap):
+    """pixareamap!(pixareas) -- enmap_ops.jl:124-138."""
+    shape, wcs = pixareas.shape, pixareas.wcs
+    _require_car(wcs)
+    data = _dev_f64(pixareas.data, "pixareas")
+    nplanes = data.shape[0] if data.dim() == 3 else 1
+    with torch.cuda.device(data.device):
+        for c in range(nplanes):
+            plane = data[c] if data.dim() == 3 else data
+            _lib.check(_lib.load().pxl_pixareamap_car_f64(_wcs_ref(wcs), _shape2(shape), 0, shape[1], _ptr(plane),
+                                                          _stream(data)))
+    return pixareas
+
+
+def pixareamap(m, wcs=None, device="cuda"):
+    """pixareamap(m::Enmap) / pixareamap(shape, wcs) -- car_proj.jl:264-272."""
+    if isinstance(m, Enmap):
+        return pixareamap_(m.similar())
+    shape = tuple(m)
+    data = torch.empty(tuple(reversed(shape)), dtype=torch.float64, device=device)
+    return pixareamap_(Enmap(data, wcs))
+
+
+# ---- reprojection -------------------------------------------------------------------------------
+
+class ReprojectPlan:
+    """Owns a pxl_reproject_plan (device coordinate tables).  src/dst windows describe declination
+    strips of sharded maps (0-based row0, nrows); full maps by default."""
+
+    def __init__(self, shape_in, wcs_in, shape_out, wcs_out, src_rows=None, dst_rows=None, device="cuda"):
+        _require_car(wcs_in)
+        _require_car(wcs_out)
+        self.shape_in = (int(shape_in[0]), int(shape_in[1]), int(shape_in[2]) if len(shape_in) > 2 else 1)
+        self.shape_out = (int(shape_out[0]), int(shape_out[1]))
+        self.wcs_in, self.wcs_out = wcs_in, wcs_out
+        self.src_rows = (0, self.shape_in[1]) if src_rows is None else (int(src_rows[0]), int(src_rows[1]))
+        self.dst_rows = (0, self.shape_out[1]) if dst_rows is None else (int(dst_rows[0]), int(dst_rows[1]))
+        self.device = torch.device(device)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().pxl_reproject_plan_create(
+                _wcs_ref(wcs_in), _lib.shape_arr(self.shape_in), self.src_rows[0], self.src_rows[1],
+                _wcs_ref(wcs_out), _lib.shape_arr(self.shape_out), self.dst_rows[0], self.dst_rows[1],
+                C.byref(self._h)))
+
+    @property
+    def ncomp(self):
+        return self.shape_in[2]
+
+    def src_tensor_shape(self):
+        return (self.ncomp, self.src_rows[1], self.shape_in[0])
+
+    def dst_tensor_shape(self):
+        return (self.ncomp, self.dst_rows[1], self.shape_out[0])
+
+    def set_variant(self, variant: int):
+        _lib.check(_lib.load().pxl_reproject_plan_set_variant(self._h, int(variant)))
+
+    def src_rows_needed(self):
+        lo, hi = C.c_int64(), C.c_int64()
+        _lib.check(_lib.load().pxl_reproject_plan_src_rows(self._h, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def rows_covered(self, have_lo, have_hi):
+        lo, hi = C.c_int64(), C.c_int64()
+        _lib.check(_lib.load().pxl_reproject_plan_rows_covered(self._h, have_lo, have_hi, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def _check(self, src, dst):
+        src, dst = _dev_f64(src, "src"), _dev_f64(dst, "dst")
+        if src.numel() != self.ncomp * self.src_rows[1] * self.shape_in[0]:
+            raise ValueError("src has %d elements, plan expects %s" % (src.numel(), (self.src_tensor_shape(),)))
+        if dst.numel() != self.ncomp * self.dst_rows[1] * self.shape_out[0]:
+            raise ValueError("dst has %d elements, plan expects %s" % (dst.numel(), (self.dst_tensor_shape(),)))
+        if src.data_ptr() == dst.data_ptr():
+            raise ValueError("src and dst must not alias")
+        return src, dst
+
+    def execute(self, src, dst):
+        src, dst = self._check(src, dst)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().pxl_reproject_execute(self._h, _ptr(src), _ptr(dst), _stream(dst)))
+        return dst
+
+    def build_tables(self):
+        with torch.cuda.device(self.device):
+            s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(_lib.load().pxl_reproject_build_tables(self._h, s))
+
+    def execute_rows(self, src, dst, r0, nr):
+        src, dst = self._check(src, dst)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().pxl_reproject_execute_rows(self._h, _ptr(src), _ptr(dst), r0, nr, _stream(dst)))
+        return dst
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.load().pxl_reproject_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def reproject(m: Enmap, shape_out, wcs_out, out: Enmap = None, plan: ReprojectPlan = None) -> Enmap:
+    """Bilinear CAR -> CAR reprojection of every component of `m` onto (shape_out, wcs_out).
+    Not in the reference; composes posmap(out) o sky2pix(in) o 2x2 gather + lerp."""
+    if plan is None:
+        plan = ReprojectPlan(m.shape, m.wcs, shape_out, wcs_out, device=m.device)
+    nxo, nyo = int(shape_out[0]), int(shape_out[1])
+    if out is None:
+        oshape = (nyo, nxo) if m.data.dim() == 2 else (m.data.shape[0], nyo, nxo)
+        out = Enmap(torch.empty(oshape, dtype=torch.float64, device=m.device), wcs_out)
+    plan.execute(m.data, out.data)
+    return out
+
+
+def sample_bilinear(m: Enmap, skycoords: torch.Tensor, src_rows=None, full_shape=None) -> torch.Tensor:
+    """Bilinear sample of every component of `m` at a 2xN batch of (ra, dec): fused
+    sky2pix!(safe=true) [car_proj.jl:165-193] + 2x2 gather.  Returns a (nc, N) tensor.
+    src_rows/full_shape describe `m.data` as a declination strip of a larger map."""
+    sky = _dev_f64(skycoords, "skycoords")
+    data = _dev_f64(m.data, "map data")
+    _require_car(m.wcs)
+    shape = m.shape if full_shape is None else tuple(full_shape)
+    nc = data.shape[0] if data.dim() == 3 else 1
+    row0, nrows = (0, shape[1]) if src_rows is None else src_rows
+    out = torch.empty((nc, sky.shape[0]), dtype=torch.float64, device=sky.device)
+    with torch.cuda.device(sky.device):
+        _lib.check(_lib.load().pxl_sample_car_bilinear_f64(
+            _wcs_ref(m.wcs), _lib.shape_arr((shape[0], shape[1], nc)), _ptr(data), row0, nrows, sky.shape[0],
+            _ptr(sky), _ptr(out), _stream(sky)))
+    return out
+
+
+# ---- synthetic inputs (benchmark plumbing) --------------------------------------------------------
+
+def fill_random_(t: torch.Tensor, seed: int, offset: int = 0, kind: str = "normal"):
+    t = _dev_f64(t, "tensor")
+    with torch.cuda.device(t.device):
+        _lib.check(_lib.load().pxl_fill_random_f64(_ptr(t), t.numel(), seed, offset, 0 if kind == "normal" else 1,
+                                                   _stream(t)))
+    return t
+
+
+def fill_sphere_points_(sky: torch.Tensor, seed: int, offset: int = 0):
+    sky = _dev_f64(sky, "skycoords")
+    with torch.cuda.device(sky.device):
+        _lib.check(_lib.load().pxl_fill_sphere_points_f64(_ptr(sky), sky.shape[0], seed, offset, _stream(sky)))
+    return sky

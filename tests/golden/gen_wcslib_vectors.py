@@ -1,0 +1,65 @@
+"""Generate wcslib golden vectors for the CAR fast path (mirrors /root/reference test/test_geometry.jl:66-80,
+where the reference itself cross-checks its CAR evaluators against wcslib through WCS.jl).
+
+Run ONCE in the authoring container with the conda interpreter that bundles astropy 4.3.1 / wcslib 7.6:
+    /opt/conda/bin/python3.9 tests/golden/gen_wcslib_vectors.py
+Only the resulting JSON (data) is committed and used by tests; nothing here runs on the GPU box.
+"""
+import json
+import os
+
+import numpy as np
+
+for _n, _v in (("asscalar", lambda a: a.item()), ("alen", len), ("float", float), ("int", int),
+               ("bool", bool), ("object", object), ("complex", complex), ("str", str)):
+    if not hasattr(np, _n):
+        setattr(np, _n, _v)          # names astropy 4.3 expects and numpy >= 1.24 removed
+import astropy.wcs as awcs  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def hexs(a):
+    return [float(v).hex() for v in np.asarray(a, dtype=np.float64).ravel()]
+
+
+def main():
+    rng = np.random.default_rng(20261003)
+    out = {"wcslib_version": awcs._wcs.__version__, "cases": []}
+    # 1-degree full-sky CC geometry (the one test_geometry.jl:50 uses) and a 0.5' box geometry (test_geometry.jl:22-27)
+    geoms = [
+        dict(name="fullsky_1deg", shape=[360, 181], cdelt=[-1.0, 1.0], crpix=[180.5, 91.0], crval=[0.5, 0.0]),
+        dict(name="box_0.5arcmin", shape=[2400, 1200], cdelt=[-0.008333333333333333, 0.008333333333333333],
+             crpix=[1201.0, 601.0], crval=[0.0, 0.0]),
+    ]
+    for g in geoms:
+        W = awcs.WCS(naxis=2)
+        W.wcs.ctype = ["RA---CAR", "DEC--CAR"]
+        W.wcs.cdelt = g["cdelt"]; W.wcs.crpix = g["crpix"]; W.wcs.crval = g["crval"]
+        nx, ny = g["shape"]
+        n = 1024
+        pix = np.stack([1 + (nx - 1) * rng.random(n), 1 + (ny - 1) * rng.random(n)], axis=1)
+        sky_deg = W.wcs_pix2world(pix, 1)
+        # on-sky points that land inside the map, so wcslib's own wrapping conventions never kick in
+        sky2_deg = W.wcs_pix2world(np.stack([1 + (nx - 1) * rng.random(n), 1 + (ny - 1) * rng.random(n)], axis=1), 1)
+        pix2 = W.wcs_world2pix(sky2_deg, 1)
+        # the reference's own draw (test_geometry.jl:67,75): pi .* rand(2, 1024), no wrap is ever involved
+        pix_small = np.pi * rng.random((n, 2))
+        sky_small_deg = W.wcs_pix2world(pix_small, 1)
+        keep = np.all(np.isfinite(sky_small_deg), axis=1)      # astropy's wcslib returns NaN below the pole
+        pix_small, sky_small_deg = pix_small[keep], sky_small_deg[keep]
+        world_small_deg = np.rad2deg(np.stack([np.pi * rng.random(n), 0.5 * np.pi * rng.random(n)], axis=1))
+        pix_from_small = W.wcs_world2pix(world_small_deg, 1)
+        assert np.all(np.isfinite(sky_deg)) and np.all(np.isfinite(pix2))
+        assert np.all(np.isfinite(sky_small_deg)) and np.all(np.isfinite(pix_from_small))
+        out["cases"].append(dict(geom=g, pix=hexs(pix), pix2world_deg=hexs(sky_deg),
+                                 world_deg=hexs(sky2_deg), world2pix=hexs(pix2),
+                                 pix_small=hexs(pix_small), pix2world_small_deg=hexs(sky_small_deg),
+                                 world_small_deg=hexs(world_small_deg), world2pix_small=hexs(pix_from_small)))
+    with open(os.path.join(HERE, "wcslib_car_vectors.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote", len(out["cases"]), "cases")
+
+
+if __name__ == "__main__":
+    main()
