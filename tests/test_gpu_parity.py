@@ -1,0 +1,397 @@
+"""GPU parity: every device entry of libpixell_hip.so (called through the C ABI via the host package)
+against the CPU oracle on the same seeded inputs.  Bar: bit-exact for pix<->sky coordinate arithmetic;
+interpolated values within 1e-10 absolute (BASELINE.json north_star) -- and, because the kernels restate
+the oracle operation for operation, we additionally require them to be bit-identical."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import ARCMIN, DEG, bits_equal
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+TOL_INTERP = 1e-10       # Float64 agreement bound on interpolated values (north_star)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import pixell_jl_amd as pj
+    pj.load_library()                      # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def to_dev(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+
+
+def geoms(pj):
+    g = {}
+    g["fullsky_1deg"] = pj.fullsky_geometry(1 * DEG)
+    g["fullsky_odd"] = ((45, 23), pj.CarClenshawCurtis((-8.0, 8.181818181818182), (22.5, 12.0), (4.0, 0.0)))
+    g["box"] = pj.geometry([[10 * DEG, -10 * DEG], [-5 * DEG, 5 * DEG]], 0.5 * ARCMIN)
+    g["box_flipped"] = pj.geometry([[-10 * DEG, 10 * DEG], [5 * DEG, -5 * DEG]], 1 * ARCMIN)
+    g["fejer1"] = ((360, 180), pj.CarFejer1((-1.0, 1.0), (180.5, 90.5), (0.5, 0.0)))
+    return g
+
+
+# ---- elementwise evaluators -----------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [0, 1, 63, 1000, 70001])
+def test_pix2sky_2xN_bit_exact(pj, O, dev, n):
+    rng = np.random.default_rng(100 + n)
+    for name, (shape, wcs) in geoms(pj).items():
+        pix = np.stack([rng.uniform(-50, shape[0] + 50, n), rng.uniform(-50, shape[1] + 50, n)], axis=1)
+        pix_d = to_dev(pix.reshape(n, 2), dev)
+        got = pj.pix2sky((shape, wcs), pix_d, safe=False).cpu().numpy()
+        assert bits_equal(got, O.pix2sky(wcs, pix.reshape(n, 2), O.WRAP_NONE)), name
+        got = pj.pix2sky_rewind((shape, wcs), pix_d).cpu().numpy()
+        assert bits_equal(got, O.pix2sky(wcs, pix.reshape(n, 2), O.WRAP_REWIND)), name
+        # safe=true on arrays = rewind + unwrap along the point axis
+        got = pj.pix2sky((shape, wcs), pix_d, safe=True).cpu().numpy()
+        assert bits_equal(got, O.pix2sky(wcs, pix.reshape(n, 2), O.WRAP_UNWIND)), name
+
+
+def test_pix2sky_inplace(pj, O, dev):
+    shape, wcs = pj.fullsky_geometry(1 * DEG)
+    rng = np.random.default_rng(1)
+    pix = rng.uniform(0, 400, (5000, 2))
+    buf = to_dev(pix, dev)
+    out = pj.pix2sky_((shape, wcs), buf, buf, safe=False)
+    assert out.data_ptr() == buf.data_ptr()
+    assert bits_equal(buf.cpu().numpy(), O.pix2sky(wcs, pix, O.WRAP_NONE))
+
+
+def test_pix2sky_soa_bit_exact(pj, O, dev):
+    rng = np.random.default_rng(2)
+    for name, (shape, wcs) in geoms(pj).items():
+        ip = rng.uniform(-3 * shape[0], 3 * shape[0], 33333)
+        jp = rng.uniform(-3 * shape[1], 3 * shape[1], 33333)
+        for safe in (True, False):
+            ra, dec = pj.pix2sky((shape, wcs), to_dev(ip, dev), to_dev(jp, dev), safe=safe)
+            era, edec = O.pix2sky_soa(wcs, ip, jp, safe=safe)
+            assert bits_equal(ra.cpu().numpy(), era) and bits_equal(dec.cpu().numpy(), edec), (name, safe)
+
+
+@pytest.mark.parametrize("safe", [True, False])
+def test_sky2pix_all_forms_bit_exact(pj, O, dev, safe):
+    rng = np.random.default_rng(3)
+    n = 50001
+    for name, (shape, wcs) in geoms(pj).items():
+        # on-sky, off-sky and "crazy" angles many periods away (test_geometry.jl:63-64)
+        ra = np.concatenate([rng.uniform(-math.pi, math.pi, n), rng.uniform(-40 * math.pi, 40 * math.pi, n)])
+        dec = np.concatenate([rng.uniform(-math.pi / 2, math.pi / 2, n), rng.uniform(-17 * math.pi, 17 * math.pi, n)])
+        sky = np.stack([ra, dec], axis=1)
+        got = pj.sky2pix((shape, wcs), to_dev(sky, dev), safe=safe).cpu().numpy()            # A11
+        assert bits_equal(got, O.sky2pix(wcs, shape, sky, safe=safe, form=O.FORM_RECIP)), name
+        x, y = pj.sky2pix((shape, wcs), to_dev(ra, dev), to_dev(dec, dev), safe=safe)         # A13
+        ex, ey = O.sky2pix_soa(wcs, shape, ra, dec, safe=safe, form=O.FORM_RECIP_AV)
+        assert bits_equal(x.cpu().numpy(), ex) and bits_equal(y.cpu().numpy(), ey), name
+        x, y = pj.sky2pix_broadcast((shape, wcs), to_dev(ra, dev), to_dev(dec, dev), safe=safe)   # A12
+        ex, ey = O.sky2pix_soa(wcs, shape, ra, dec, safe=safe, form=O.FORM_DIV)
+        assert bits_equal(x.cpu().numpy(), ex) and bits_equal(y.cpu().numpy(), ey), name
+
+
+def test_device_matches_host_scalar_methods(pj, dev):
+    """The host scalar methods (which stay on the CPU, as in the reference) and the device broadcast form
+    are the same arithmetic."""
+    shape, wcs = pj.fullsky_geometry(1 * DEG)
+    rng = np.random.default_rng(4)
+    ra = rng.uniform(-10, 10, 257)
+    dec = rng.uniform(-3, 3, 257)
+    x, y = pj.sky2pix_broadcast((shape, wcs), to_dev(ra, dev), to_dev(dec, dev), safe=True)
+    host = np.array([pj.sky2pix((shape, wcs), float(a), float(d)) for a, d in zip(ra, dec)])
+    assert bits_equal(x.cpu().numpy(), host[:, 0]) and bits_equal(y.cpu().numpy(), host[:, 1])
+    a, d = pj.pix2sky((shape, wcs), to_dev(ra * 20, dev), to_dev(dec * 20, dev), safe=True)
+    host = np.array([pj.pix2sky((shape, wcs), float(i), float(j)) for i, j in zip(ra * 20, dec * 20)])
+    assert bits_equal(a.cpu().numpy(), host[:, 0]) and bits_equal(d.cpu().numpy(), host[:, 1])
+
+
+def test_reference_literals_on_device(pj, dev, literals):
+    """The reference's known answers through the device path (test_geometry.jl:52-64,82-87)."""
+    shape, wcs = pj.fullsky_geometry(1 * DEG)
+    pix = np.array([lit["pix"] for lit in literals["pix2sky_1deg"]])
+    sky = pj.pix2sky_rewind((shape, wcs), to_dev(pix, dev)).cpu().numpy()
+    for row, lit in zip(sky, literals["pix2sky_1deg"]):
+        assert np.allclose(row, lit["sky"], rtol=1.5e-8, atol=0), lit["src"]
+    lit = literals["wrap_box_1deg"]
+    b = lit["box_deg"]
+    shape, wcs = pj.geometry([[b[0][0] * DEG, b[0][1] * DEG], [b[1][0] * DEG, b[1][1] * DEG]], lit["res_deg"] * DEG)
+    ra = np.array(lit["ra_deg"], dtype=float) * DEG
+    x, _ = pj.sky2pix_broadcast((shape, wcs), to_dev(ra, dev), to_dev(np.zeros_like(ra), dev), safe=True)
+    assert np.allclose(x.cpu().numpy(), lit["pix_ra"], rtol=1.5e-8)
+
+
+def test_wcslib_vectors_on_device(pj, dev, wcslib_vectors):
+    from conftest import unhex, isapprox
+    for case in wcslib_vectors["cases"]:
+        g = case["geom"]
+        wcs = pj.CarClenshawCurtis(g["cdelt"], g["crpix"], g["crval"])
+        sky = pj.pix2sky((g["shape"], wcs), to_dev(unhex(case["pix_small"]), dev), safe=False).cpu().numpy()
+        assert isapprox(sky, unhex(case["pix2world_small_deg"]) * DEG)
+        pix = pj.sky2pix((g["shape"], wcs), to_dev(unhex(case["world_small_deg"]) * DEG, dev), safe=False).cpu().numpy()
+        assert isapprox(pix, unhex(case["world2pix_small"]))
+
+
+# ---- whole-map writers ----------------------------------------------------------------------------
+
+def test_posmap_bit_exact(pj, O, dev):
+    for name, (shape, wcs) in geoms(pj).items():
+        if shape[0] * shape[1] > 4_000_000:
+            continue
+        ra, dec = pj.posmap(shape, wcs, device=dev)
+        era, edec = O.posmap(wcs, shape)
+        assert ra.shape == shape and bits_equal(ra.data.cpu().numpy(), era), name
+        assert bits_equal(dec.data.cpu().numpy(), edec), name
+        # safe=false and a strip
+        ra, dec = pj.posmap(shape, wcs, device=dev, row0=3, nrows=7, safe=False)
+        era, edec = O.posmap(wcs, shape, row0=3, nrows=7, safe=False)
+        assert bits_equal(ra.data.cpu().numpy(), era) and bits_equal(dec.data.cpu().numpy(), edec), name
+
+
+def test_posmap_range_invariants_fullsky(pj, dev):
+    """test_geometry.jl:207-223 on device."""
+    shape, wcs = pj.fullsky_geometry(1 * DEG)
+    ra, dec = pj.posmap(shape, wcs, device=dev)
+    assert float(ra.data.min()) >= -math.pi and float(ra.data.max()) <= math.pi
+    assert float(dec.data.min()) >= -math.pi / 2 and float(dec.data.max()) <= math.pi / 2
+    sky = torch.stack([ra.data.reshape(-1), dec.data.reshape(-1)], dim=1).contiguous()
+    pix = pj.sky2pix((shape, wcs), sky, safe=True)
+    assert float(pix[:, 0].min()) >= 1 and float(pix[:, 0].max()) <= shape[0]
+    assert float(pix[:, 1].min()) >= 1 and float(pix[:, 1].max()) <= shape[1]
+
+
+def test_pixareamap_vs_reference_data(pj, O, dev, literals):
+    """test_geometry.jl:287-316: first column vs the python-pixell data files, sum|diff| < 100 eps."""
+    import os
+    from conftest import GOLDEN
+    for lit in literals["pixareamap"]:
+        if lit["kind"] == "fullsky_1deg":
+            shape, wcs = pj.fullsky_geometry(1 * DEG)
+        else:
+            b = lit["box_deg"]
+            shape, wcs = pj.geometry([[b[0][0] * DEG, b[0][1] * DEG], [b[1][0] * DEG, b[1][1] * DEG]],
+                                     lit["res_arcmin"] * ARCMIN)
+        pm = pj.pixareamap(shape, wcs, device=dev)
+        col = pm.data[:, 0].cpu().numpy()
+        ref = np.loadtxt(os.path.join(GOLDEN, lit["file"]))
+        assert np.abs(col - ref).sum() < lit["tol_sum_abs"], lit["src"]
+        # device sin vs glibc sin: a few ulp of sin(dec) ~ 1, scaled by the RA pixel width
+        assert np.abs(col - O.pixarea_rows(wcs, shape[1])).max() < 8 * np.finfo(float).eps * abs(wcs.cdelt[0] * wcs.unit)
+        assert bool((pm.data == pm.data[:, :1]).all())          # constant along RA
+        m = pj.Enmap(torch.zeros((shape[1], shape[0]), dtype=torch.float64, device=dev), wcs)
+        assert np.abs(pj.pixareamap(m).data[:, 0].cpu().numpy() - ref).sum() < lit["tol_sum_abs"]
+
+
+def test_gnomonic_on_device(pj, O, dev, literals):
+    """test_geometry.jl:92-119: device TAN evaluators vs the oracle (libm-level tolerance), literals, and
+    the full posmap of the 1827x1825 patch with the reference's own L1 bound (sum|diff| < 1e-9)."""
+    g = literals["gnomonic"]
+    wcs = pj.Gnomonic(g["cdelt"], g["crpix"], g["crval"])
+    shape = tuple(g["shape"])
+    for lit in g["pix2sky"]:
+        a, d = pj.pix2sky((shape, wcs), float(lit["pix"][0]), float(lit["pix"][1]))
+        assert np.allclose([a, d], lit["sky"], rtol=1.5e-8)
+    ra, dec = pj.posmap(shape, wcs, device=dev)
+    jj, ii = np.meshgrid(np.arange(1, shape[1] + 1, dtype=float), np.arange(1, shape[0] + 1, dtype=float), indexing="ij")
+    era, edec = O.pix2sky_tan(wcs, ii.ravel(), jj.ravel())
+    assert np.abs(ra.data.cpu().numpy().ravel() - era).sum() < 1e-9
+    assert np.abs(dec.data.cpu().numpy().ravel() - edec).sum() < 1e-9
+    x, y = pj.sky2pix((shape, wcs), to_dev(era, dev), to_dev(edec, dev))
+    assert np.abs(x.cpu().numpy() - ii.ravel()).max() < 1e-6 and np.abs(y.cpu().numpy() - jj.ravel()).max() < 1e-6
+    ex, ey = O.sky2pix_tan(wcs, era, edec)
+    assert np.abs(x.cpu().numpy() - ex).max() < 1e-7 and np.abs(y.cpu().numpy() - ey).max() < 1e-7
+
+
+# ---- reprojection ---------------------------------------------------------------------------------
+
+def _shifted(pj, wcs, dx, dy):
+    return type(wcs)(wcs.cdelt, (wcs.crpix[0] + dx, wcs.crpix[1] + dy), wcs.crval, wcs.unit)
+
+
+def reproject_cases(pj):
+    fs64 = pj.fullsky_geometry(2 * math.pi / 64)
+    fs128 = pj.fullsky_geometry(2 * math.pi / 128)
+    fs256 = pj.fullsky_geometry(2 * math.pi / 256)
+    fs500 = pj.fullsky_geometry(2 * math.pi / 500)
+    fs1000 = pj.fullsky_geometry(2 * math.pi / 1000)
+    odd = ((45, 23), pj.CarClenshawCurtis((-8.0, 8.181818181818182), (22.5, 12.0), (4.0, 0.0)))
+    box = pj.geometry([[10 * DEG, -10 * DEG], [-5 * DEG, 5 * DEG]], 2 * ARCMIN)
+    box_fine = pj.geometry([[6 * DEG, -7 * DEG], [-3 * DEG, 4 * DEG]], 1 * ARCMIN)
+    box_flip = pj.geometry([[-8 * DEG, 9 * DEG], [4 * DEG, -4 * DEG]], 1.5 * ARCMIN)
+    wide = pj.geometry([[179 * DEG, -179 * DEG], [-60 * DEG, 60 * DEG]], 30 * ARCMIN)
+    cases = {
+        "refine2x_fullsky": (fs128, fs256),                     # the headline pattern (config 2/3)
+        "refine2x_to_1000": (fs500, fs1000),
+        "same_res_half_pixel_shift": (fs256, (fs256[0], _shifted(pj, fs256[1], 0.5, 0.5))),   # config 4 pattern
+        "same_res_quarter_shift": (fs500, (fs500[0], _shifted(pj, fs500[1], -0.25, 0.3))),
+        "identity": (fs128, fs128),
+        "coarsen2x": (fs256, fs128),
+        "coarsen4x": (fs256, fs64),
+        "refine8x": (fs64, (fs500[0], fs500[1])),
+        "odd_nx_source": (odd, fs128),
+        "odd_nx_dest": (fs128, odd),
+        "fullsky_to_box": (fs1000, box),
+        "box_to_box_fine": (box, box_fine),
+        "box_to_flipped_box": (box, box_flip),
+        "flipped_box_to_box": (box_flip, box),
+        "box_to_fullsky_mostly_zero": (box, fs256),
+        "wide_box_to_fullsky": (wide, fs500),                  # non-periodic source, rewind jump inside tiles
+        "fullsky_to_wide": (fs500, wide),
+    }
+    return cases
+
+
+@pytest.mark.parametrize("ncomp", [1, 3])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_reproject_vs_oracle(pj, O, dev, ncomp, variant):
+    rng = np.random.default_rng(42)
+    for name, ((shape_in, wcs_in), (shape_out, wcs_out)) in reproject_cases(pj).items():
+        nx, ny = shape_in[:2]
+        src = rng.normal(size=(ncomp, ny, nx))
+        expect = O.reproject(wcs_in, (nx, ny, ncomp), src, wcs_out, shape_out)
+        plan = pj.ReprojectPlan((nx, ny, ncomp), wcs_in, shape_out, wcs_out, device=dev)
+        plan.set_variant(variant)
+        dst = torch.full(plan.dst_tensor_shape(), float("nan"), dtype=torch.float64, device=dev)
+        plan.execute(to_dev(src, dev), dst)
+        got = dst.cpu().numpy()
+        assert np.isfinite(got).all(), name
+        err = np.abs(got - expect).max()
+        assert err <= TOL_INTERP, (name, variant, err)
+        assert bits_equal(got, expect), (name, variant, "not bit-identical", err)
+        plan.close()
+
+
+def test_reproject_enmap_api(pj, O, dev):
+    (shape_in, wcs_in), (shape_out, wcs_out) = reproject_cases(pj)["refine2x_fullsky"]
+    rng = np.random.default_rng(5)
+    src = rng.normal(size=(shape_in[1], shape_in[0]))
+    m = pj.Enmap(to_dev(src, dev), wcs_in)
+    out = pj.reproject(m, shape_out, wcs_out)
+    assert out.shape == shape_out and out.wcs == wcs_out
+    expect = O.reproject(wcs_in, shape_in, src[None], wcs_out, shape_out)[0]
+    assert bits_equal(out.data.cpu().numpy(), expect)
+
+
+@pytest.mark.parametrize("rh", [1, 5, 64])
+def test_reproject_tile_heights(pj, O, dev, rh, monkeypatch):
+    """Different tile heights / lane widths walk the LDS ring differently; results must not change."""
+    for pairs in (1, 2):
+        monkeypatch.setenv("PXL_REPROJECT_RH", str(rh))
+        monkeypatch.setenv("PXL_REPROJECT_PAIRS", str(pairs))
+        rng = np.random.default_rng(6)
+        for name in ("refine2x_to_1000", "same_res_quarter_shift", "coarsen2x", "box_to_flipped_box"):
+            (shape_in, wcs_in), (shape_out, wcs_out) = reproject_cases(pj)[name]
+            src = rng.normal(size=(1, shape_in[1], shape_in[0]))
+            plan = pj.ReprojectPlan(shape_in, wcs_in, shape_out, wcs_out, device=dev)
+            dst = torch.empty(plan.dst_tensor_shape(), dtype=torch.float64, device=dev)
+            plan.execute(to_dev(src, dev), dst)
+            assert bits_equal(dst.cpu().numpy(), O.reproject(wcs_in, shape_in, src, wcs_out, shape_out)), (name, rh, pairs)
+
+
+def test_reproject_windows(pj, O, dev):
+    """Dec-strip windows: a shard that holds only the rows it needs gives the same bits as the full map,
+    and execute_rows() can split a strip into interior + boundary launches."""
+    (shape_in, wcs_in), (shape_out, wcs_out) = reproject_cases(pj)["same_res_quarter_shift"]
+    nx, ny = shape_in
+    rng = np.random.default_rng(8)
+    src = rng.normal(size=(3, ny, nx))
+    full = O.reproject(wcs_in, (nx, ny, 3), src, wcs_out, shape_out)
+    nyo = shape_out[1]
+    for lo, hi in ((0, 60), (60, 200), (200, nyo)):
+        probe = pj.ReprojectPlan((nx, ny, 3), wcs_in, shape_out, wcs_out, dst_rows=(lo, hi - lo), device=dev)
+        s_lo, s_hi = probe.src_rows_needed()
+        assert (s_lo, s_hi) == O.reproject_src_rows(wcs_in, shape_in, wcs_out, shape_out, lo, hi - lo)
+        plan = pj.ReprojectPlan((nx, ny, 3), wcs_in, shape_out, wcs_out, src_rows=(s_lo, s_hi - s_lo),
+                                dst_rows=(lo, hi - lo), device=dev)
+        s = to_dev(src[:, s_lo:s_hi], dev)
+        dst = torch.empty(plan.dst_tensor_shape(), dtype=torch.float64, device=dev)
+        plan.execute(s, dst)
+        assert bits_equal(dst.cpu().numpy(), full[:, lo:hi])
+        dst2 = torch.full_like(dst, float("nan"))
+        plan.build_tables()
+        mid = (hi - lo) // 3
+        plan.execute_rows(s, dst2, mid, (hi - lo) - mid)
+        plan.execute_rows(s, dst2, 0, mid)
+        assert bits_equal(dst2.cpu().numpy(), full[:, lo:hi])
+
+
+def test_reproject_properties_linearity(pj, dev):
+    """Size-independent property: reproject is linear in the map (exactly, for power-of-two scalings)."""
+    (shape_in, wcs_in), (shape_out, wcs_out) = reproject_cases(pj)["refine2x_to_1000"]
+    g = torch.Generator(device="cpu").manual_seed(1)
+    a = torch.randn((shape_in[1], shape_in[0]), dtype=torch.float64, generator=g).to(dev)
+    plan = pj.ReprojectPlan(shape_in, wcs_in, shape_out, wcs_out, device=dev)
+    ra = pj.reproject(pj.Enmap(a, wcs_in), shape_out, wcs_out, plan=plan).data
+    r4 = pj.reproject(pj.Enmap(4.0 * a, wcs_in), shape_out, wcs_out, plan=plan).data
+    assert torch.equal(r4, 4.0 * ra)
+    ones = pj.reproject(pj.Enmap(torch.ones_like(a), wcs_in), shape_out, wcs_out, plan=plan).data
+    assert float((ones - 1.0).abs().max()) < 1e-13       # weights sum to one on a full-sky map
+
+
+# ---- scattered sampling ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("ncomp", [1, 3])
+def test_sample_bilinear_vs_oracle(pj, O, dev, ncomp):
+    rng = np.random.default_rng(9)
+    n = 20011
+    for name, (shape, wcs) in geoms(pj).items():
+        if shape[0] * shape[1] > 4_000_000:
+            continue
+        nx, ny = shape
+        src = rng.normal(size=(ncomp, ny, nx))
+        u1, u2 = rng.random(n), rng.random(n)
+        sky = np.stack([2 * math.pi * u1 - math.pi, np.arcsin(2 * u2 - 1)], axis=1)     # uniform on the sphere
+        sky[:50, 0] += 6 * math.pi                                                        # far-away periods
+        m = pj.Enmap(to_dev(src if ncomp > 1 else src[0], dev), wcs)
+        got = pj.sample_bilinear(m, to_dev(sky, dev)).cpu().numpy()
+        expect = O.sample_bilinear(wcs, (nx, ny, ncomp), src, sky)
+        assert np.abs(got - expect).max() <= TOL_INTERP, name
+        assert bits_equal(got, expect), name
+
+
+def test_sample_nonfinite_and_empty(pj, O, dev):
+    shape, wcs = pj.fullsky_geometry(2 * math.pi / 64)
+    src = np.random.default_rng(1).normal(size=(shape[1], shape[0]))
+    m = pj.Enmap(to_dev(src, dev), wcs)
+    sky = np.array([[0.1, 0.2], [float("nan"), 0.0], [0.3, float("inf")], [1.0, -1.0]])
+    got = pj.sample_bilinear(m, to_dev(sky, dev)).cpu().numpy()[0]
+    expect = O.sample_bilinear(wcs, (shape[0], shape[1], 1), src[None], sky)[0]
+    assert np.isnan(got[1]) and np.isnan(got[2]) and np.isnan(expect[1]) and np.isnan(expect[2])
+    assert got[0] == expect[0] and got[3] == expect[3]
+    empty = pj.sample_bilinear(m, torch.empty((0, 2), dtype=torch.float64, device=dev))
+    assert empty.shape == (1, 0)
+
+
+def test_sample_matches_reproject(pj, dev):
+    """Consistency of the two samplers: sampling at the output pixel centres of a reprojection gives the
+    reprojected map to rounding (they use the reference's two different sky2pix roundings)."""
+    (shape_in, wcs_in), (shape_out, wcs_out) = reproject_cases(pj)["same_res_quarter_shift"]
+    g = torch.Generator(device="cpu").manual_seed(2)
+    a = torch.randn((shape_in[1], shape_in[0]), dtype=torch.float64, generator=g).to(dev)
+    m = pj.Enmap(a, wcs_in)
+    rep = pj.reproject(m, shape_out, wcs_out).data
+    ra, dec = pj.posmap(shape_out, wcs_out, device=dev, safe=False)
+    sky = torch.stack([ra.data.reshape(-1), dec.data.reshape(-1)], dim=1).contiguous()
+    smp = pj.sample_bilinear(m, sky).reshape(rep.shape)
+    assert float((smp - rep).abs().max()) < 1e-9
+
+
+# ---- error behaviour ------------------------------------------------------------------------------
+
+def test_errors_are_reported_not_swallowed(pj, dev):
+    shape, wcs = pj.fullsky_geometry(1 * DEG)
+    with pytest.raises(RuntimeError):                      # CPU tensors are refused: no CPU fallback
+        pj.pix2sky((shape, wcs), torch.zeros((4, 2), dtype=torch.float64))
+    with pytest.raises(TypeError):
+        pj.pix2sky((shape, wcs), torch.zeros((4, 2), dtype=torch.float32, device=dev))
+    bad = pj.CarClenshawCurtis((0.0, 1.0), (1.0, 1.0), (0.0, 0.0))
+    with pytest.raises(pj.PixellHipError) as ei:
+        pj.pix2sky((shape, bad), torch.zeros((4, 2), dtype=torch.float64, device=dev))
+    assert ei.value.code == -22 and "WCS" in str(ei.value)
+    with pytest.raises(pj.PixellHipError):
+        pj.ReprojectPlan(shape, wcs, shape, wcs, dst_rows=(100, 500), device=dev)
+    with pytest.raises(AssertionError):                    # car_proj.jl:156
+        pj.pix2sky((shape, wcs), [1.0, 2.0, 3.0])
