@@ -1,0 +1,298 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Float64 CAR bilinear reprojection throughput (Mpix/s) and fraction of
+the MI355X HBM roofline, at 1/2/4/8 GPUs of one node (strong scaling, dec-strip sharding, RCCL halo).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg3|cfg2|cfg5]
+
+For N > 1 launch one rank per GPU:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over the whole synthetic map (inputs resident in HBM): halo exchange
+(N > 1) + coordinate-table build + reprojection of every component.  Rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json configs; natural Clenshaw-Curtis shapes, ny = nx/2 + 1):
+    cfg4 (default): (43200, 21601, 3) IQU -> same shape, half-pixel-shifted WCS; 16 B per output value.
+                    This is the configuration north_star quotes the metric on ("full-sky 0.5-arcmin CAR
+                    bilinear reprojection", ">= 6x strong scaling to 8 GPUs"); it fits one GPU (44.8 GB).
+    cfg3: (21600, 10801) -> (43200, 21601) 2x refinement, 10 B per output pixel.
+    cfg2: (4096, 2049) -> (8192, 4097) (Infinity-Cache resident; informational).
+    cfg5: 1e9 scattered (ra, dec) points sampled from a (43200, 21601) map replicated per GPU.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch                      # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import pixell_jl_amd as pj        # noqa: E402
+
+HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def workload_geometry(name):
+    if name == "cfg4":
+        shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 43200, dims=(3,))
+        shape_out = shape_in[:2]
+        wcs_out = pj.CarClenshawCurtis(wcs_in.cdelt, (wcs_in.crpix[0] + 0.5, wcs_in.crpix[1] + 0.5), wcs_in.crval)
+        desc = "cfg4: 43200x21601x3 IQU Float64 full-sky CAR -> same shape, half-pixel-shifted WCS (0.5 arcmin)"
+    elif name == "cfg3":
+        shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 21600)
+        shape_out, wcs_out = pj.fullsky_geometry(2 * math.pi / 43200)
+        desc = "cfg3: 21600x10801 I-only Float64 full-sky CAR -> 2x-refined 43200x21601"
+    elif name == "cfg2":
+        shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 4096)
+        shape_out, wcs_out = pj.fullsky_geometry(2 * math.pi / 8192)
+        desc = "cfg2: 4096x2049 Float64 full-sky CAR -> 2x-refined 8192x4097 (cache resident)"
+    else:
+        raise ValueError(name)
+    nc = shape_in[2] if len(shape_in) > 2 else 1
+    return (shape_in[0], shape_in[1], nc), wcs_in, shape_out, wcs_out, desc
+
+
+def fill_strip(sh, src, seed):
+    """Deterministic N(0,1) map values keyed by (component, absolute pixel index): only the rows this rank
+    OWNS are generated; halo rows must arrive through the exchange."""
+    nx, ny, nc = sh.shape_in
+    own_lo, own_hi = sh.own[sh.rank]
+    sl = sh.own_slice()
+    for c in range(nc):
+        plane = src[c, sl, :]
+        assert plane.is_contiguous()
+        pj.fill_random_(plane, seed + c, offset=own_lo * nx, kind="normal")
+
+
+def cpu_baseline_reproject(shape_in, wcs_in, shape_out, wcs_out, budget_s=12.0):
+    """Time the CPU oracle (a C port of the reference arithmetic; the reference has no reprojection of its
+    own and Julia is not installed) on a bounded strip of the same workload."""
+    import numpy as np
+    from oracle import oracle as O
+    nx, ny, nc = shape_in
+    nxo, nyo = shape_out
+    mid = nyo // 2
+
+    def run(nrows, threads):
+        lo = mid - nrows // 2
+        s_lo, s_hi = O.reproject_src_rows(wcs_in, shape_in, wcs_out, shape_out, lo, nrows)
+        rng = np.random.default_rng(1234)
+        src = rng.random((nc, s_hi - s_lo, nx))
+        O.set_threads(threads)
+        t0 = time.perf_counter()
+        O.reproject(wcs_in, shape_in, src, wcs_out, shape_out, src_row0=s_lo, src_nrows=s_hi - s_lo, dst_row0=lo,
+                    dst_nrows=nrows)
+        dt = time.perf_counter() - t0
+        O.set_threads(1)
+        return nxo * nrows * nc / dt / 1e6
+
+    rows1 = max(8, int(2.0e8 / (nxo * nc)))                 # ~2e8 output values for the 1-core leg
+    v1 = run(rows1, 1)
+    cores = min(O.max_threads(), os.cpu_count() or 1)
+    rowsN = max(rows1, int(min(budget_s * v1 * 1e6 * cores * 0.5, 1.5e9) / (nxo * nc)))
+    rowsN = min(rowsN, nyo // 2)
+    vN = run(rowsN, cores)
+    return {"value": round(vN, 1), "unit": "Mpix/s", "cores": cores, "kind": "port",
+            "value_1core": round(v1, 1),
+            "sample": "oracle/pixell_oracle.c reproject of %d (all-core) / %d (1-core) centre output rows x %d "
+                      "columns x %d components of the same workload" % (rowsN, rows1, nxo, nc)}
+
+
+def load_traffic(workload):
+    p = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
+    if os.path.exists(p):
+        with open(p) as f:
+            return json.load(f)
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("PXL_BENCH_WORKLOAD", "cfg4"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="verify a sample of the output against the oracle")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        sys.exit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    pj.load_library()
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.workload == "cfg5":
+        result = bench_scattered(args, rank, world, dev)
+    else:
+        result = bench_reproject(args, rank, world, dev)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def timed_region(world, dev, steps, body):
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        body(k)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def bench_reproject(args, rank, world, dev):
+    shape_in, wcs_in, shape_out, wcs_out, desc = workload_geometry(args.workload)
+    nx, ny, nc = shape_in
+    nxo, nyo = shape_out
+    sh = pj.DecStripReprojector(shape_in, wcs_in, shape_out, wcs_out, rank, world, dev)
+    src = sh.alloc_src()
+    dst = sh.alloc_dst()
+    fill_strip(sh, src, 1234)
+    torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        sh.step(src, dst)
+    torch.cuda.synchronize(dev)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    dt = timed_region(world, dev, args.steps, lambda k: sh.step(src, dst, events=ev[k]))
+
+    out_values = nxo * nyo * nc
+    mpix = out_values * args.steps / dt / 1e6
+    # dominant kernel (k_reproject_staged): the launch bracketed by the events
+    kms = sorted(a.elapsed_time(b) for a, b in ev)
+    k_avg_ms = sum(kms) / len(kms)
+    if world == 1:
+        launch_out_rows, launch_src_rows = nyo, ny
+    else:
+        launch_out_rows = sh.interior[1] - sh.interior[0]
+        launch_src_rows = sh.own[rank][1] - sh.own[rank][0]
+    # algorithmic bytes of that launch: source rows read once + output rows written once
+    alg_bytes = 8.0 * nc * (launch_src_rows * nx + launch_out_rows * nxo)
+    achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
+    traffic = load_traffic(args.workload) if world == 1 else None
+
+    result = {
+        "metric": "Mpix/s CAR bilinear reproject (Float64)",
+        "value": round(mpix, 1), "unit": "Mpix/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": desc, "shape_in": list(shape_in), "shape_out": list(shape_out) + [nc],
+                   "parallelism": "dec-strip x%d, %d-row halo via RCCL send/recv" % (
+                       world, max([hi - lo for _, lo, hi in sh.recvs], default=0)),
+                   "halo_bytes_per_rank": sh.halo_bytes(),
+                   "bytes_per_output_value": round(8.0 * (nx * ny + nxo * nyo) / (nxo * nyo), 3)},
+        "roofline": {"bound": "hbm", "kernel": "k_reproject_staged",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "kernel_ms_avg": round(k_avg_ms, 4), "kernel_ms_min": round(kms[0], 4),
+                     "kernel_ms_median": round(kms[len(kms) // 2], 4)},
+    }
+    if args.check and rank == 0:
+        result["check"] = spot_check(sh, src, dst, shape_in, wcs_in, shape_out, wcs_out)
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        del src, dst
+        torch.cuda.empty_cache()
+        result["cpu_baseline"] = cpu_baseline_reproject(shape_in, wcs_in, shape_out, wcs_out)
+    return result
+
+
+def spot_check(sh, src, dst, shape_in, wcs_in, shape_out, wcs_out, nrows=6):
+    """Compare a few output rows of this rank's strip with the oracle fed the same source rows."""
+    import numpy as np
+    from oracle import oracle as O
+    lo, n = sh.dst_window
+    worst = 0.0
+    bit_identical = True
+    for r in sorted({0, n // 3, n // 2, n - 1}):
+        s_lo, s_hi = O.reproject_src_rows(wcs_in, shape_in, wcs_out, shape_out, lo + r, 1)
+        s = src[:, s_lo - sh.buf_lo:s_hi - sh.buf_lo, :].cpu().numpy()
+        exp = O.reproject(wcs_in, shape_in, s, wcs_out, shape_out, src_row0=s_lo, src_nrows=s_hi - s_lo,
+                          dst_row0=lo + r, dst_nrows=1)
+        got = dst[:, r:r + 1, :].cpu().numpy()
+        worst = max(worst, float(np.abs(got - exp).max()))
+        bit_identical &= bool(np.array_equal(got.view(np.int64), exp.view(np.int64)))
+    return {"max_abs_err": worst, "bit_identical": bit_identical}
+
+
+def bench_scattered(args, rank, world, dev):
+    npts_total = int(float(os.environ.get("PXL_BENCH_POINTS", "1e9")))
+    shape, wcs = pj.fullsky_geometry(2 * math.pi / 43200)
+    nx, ny = shape
+    lo, hi = pj.strip_bounds(npts_total, world, rank)
+    n = hi - lo
+    m = pj.Enmap(torch.empty((ny, nx), dtype=torch.float64, device=dev), wcs)
+    pj.fill_random_(m.data, 1234, 0, "normal")                      # replicated map
+    sky = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    pj.fill_sphere_points_(sky, 42, offset=lo)                      # uniform on the sphere, seed 42
+    out = torch.empty((1, n), dtype=torch.float64, device=dev)
+    lib = pj.load_library()
+    import ctypes as C
+    wref = wcs.to_struct()
+    shp = pj._lib.shape_arr((nx, ny, 1))
+
+    def step(k, ev=None):
+        s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        if ev:
+            ev[0].record()
+        pj._lib.check(lib.pxl_sample_car_bilinear_f64(C.byref(wref), shp, C.c_void_p(m.data.data_ptr()), 0, ny, n,
+                                                      C.c_void_p(sky.data_ptr()), C.c_void_p(out.data_ptr()), s))
+        if ev:
+            ev[1].record()
+
+    for k in range(args.warmup):
+        step(k)
+    torch.cuda.synchronize(dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    dt = timed_region(world, dev, args.steps, lambda k: step(k, ev[k]))
+    kms = sorted(a.elapsed_time(b) for a, b in ev)
+    k_avg_ms = sum(kms) / len(kms)
+    alg = 56.0 * n                                                  # 16 coords + 4x8 taps + 8 out
+    achieved = alg / (k_avg_ms * 1e-3) / 1e9
+    return {
+        "metric": "Mpts/s scattered sky2pix + bilinear sample (Float64)",
+        "value": round(npts_total * args.steps / dt / 1e6, 1), "unit": "Mpts/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "cfg5: %.3g uniform-on-sphere points sampled from a replicated 43200x21601 map" % npts_total,
+                   "parallelism": "replicated map, points sharded x%d, no collective" % world},
+        "roofline": {"bound": "hbm", "kernel": "k_sample_bilinear", "achieved": round(achieved, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": alg, "sector_granular_bytes_per_launch": 152.0 * n,
+                     "kernel_ms_avg": round(k_avg_ms, 4)},
+    }
+
+
+if __name__ == "__main__":
+    main()

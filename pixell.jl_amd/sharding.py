@@ -186,11 +186,18 @@ class DecStripReprojector(DecStripLayout):
     def alloc_dst(self):
         return torch.empty(self.dst_tensor_shape(), dtype=torch.float64, device=self.device)
 
-    def step(self, src: torch.Tensor, dst: torch.Tensor):
-        """One pass: exchange halos, reproject this rank's output strip.  Asynchronous on the current stream."""
+    def step(self, src: torch.Tensor, dst: torch.Tensor, events=None):
+        """One pass: exchange halos, reproject this rank's output strip.  Asynchronous on the current stream.
+        events = (start, end) torch.cuda.Events recorded around the dominant kernel launch (the whole
+        strip on one rank, the interior rows when sharded) for per-kernel timing."""
         nrows = self.dst_window[1]
         if self.world == 1 or (not self.sends and not self.recvs):
-            self.plan.execute(src, dst)
+            self.plan.build_tables()
+            if events:
+                events[0].record()
+            self.plan.execute_rows(src, dst, 0, nrows)
+            if events:
+                events[1].record()
             return dst
         if self._staging is None:
             self._staging = self.make_staging(src)
@@ -198,7 +205,11 @@ class DecStripReprojector(DecStripLayout):
         self.plan.build_tables()
         i_lo, i_hi = self.interior
         if i_hi > i_lo:
+            if events:
+                events[0].record()
             self.plan.execute_rows(src, dst, i_lo, i_hi - i_lo)          # overlaps the halo transfer
+            if events:
+                events[1].record()
         self.finish_halo_exchange(src, self._staging, works)
         if i_hi > i_lo:
             if i_lo > 0:
