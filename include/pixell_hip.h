@@ -135,7 +135,8 @@ int pxl_reproject_plan_src_rows(const pxl_reproject_plan* plan, int64_t* lo, int
  * [have_lo, have_hi) -- the interior that can start before a halo arrives.                           */
 int pxl_reproject_plan_rows_covered(const pxl_reproject_plan* plan, int64_t have_lo, int64_t have_hi,
                                     int64_t* lo, int64_t* hi);
-/* tuning knob for benchmarking: 0 = auto, 1 = force the direct-gather kernel, 2 = force staged */
+/* tuning knob for benchmarking / cross-checks: 0 = auto (LDS-DMA kernel when the source allows 16-B loads),
+ * 1 = direct-gather kernel, 2 = register-staged kernel */
 int pxl_reproject_plan_set_variant(pxl_reproject_plan* plan, int variant);
 int pxl_reproject_plan_destroy(pxl_reproject_plan* plan);
 

@@ -7,6 +7,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared   (see build.py)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -282,8 +283,13 @@ struct ReprojParams {
     int32_t rh;            // output rows per tile
     int32_t seg;           // LDS slot length in doubles (even)
     int32_t dxpos;         // source column increases with output column
+    int32_t dypos;         // source row increases with output row
     int32_t ntx, nty;      // tiles along RA / DEC
     int64_t ntiles, tiles_per_xcd;
+    int32_t flags;         // tuning/diagnostics: 1 = skip source loads, 2 = skip stores, 4 = no XCD remap
+    // LDS-DMA kernel only
+    int32_t ns, pf;        // ring slots (power of two), prefetch distance in output rows
+    const double* zero_page;   // 16 bytes of zeros in device memory
 };
 
 // ---- generic direct-gather kernel: one lane per output pixel pair, 4 taps from global memory each.
@@ -335,7 +341,7 @@ __device__ inline void load_row_regs(const ReprojParams& p, const double* plane,
                                      int lane, double2 (&regs)[PXL_MAXCH]) {
     // j: 1-based absolute source row (any integer).  Rows outside the map / resident window read as 0.
     int64_t jr = j - 1 - p.src_row0;
-    const bool row_ok = (j >= 1) && (j <= p.ny) && (jr >= 0) && (jr < p.src_nrows);
+    const bool row_ok = (j >= 1) && (j <= p.ny) && (jr >= 0) && (jr < p.src_nrows) && !(p.flags & 1);
     const double* rowp = plane + (row_ok ? jr : 0) * p.nx;
 #pragma unroll
     for (int ch = 0; ch < PXL_MAXCH; ++ch) {
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(64) void k_reproject_staged(ReprojParams p) {
     // contiguous run of tiles so RA-neighbouring tiles (which share 128-B lines at their edges and the
     // same source rows) hit the same L2.  Placement only affects speed, never correctness.
     const int64_t b = blockIdx.x;
-    const int64_t t = (b & 7) * p.tiles_per_xcd + (b >> 3);
+    const int64_t t = (p.flags & 4) ? b : (b & 7) * p.tiles_per_xcd + (b >> 3);
     if (t >= p.ntiles) return;
     const int tx = (int)(t % p.ntx);
     const int64_t trest = t / p.ntx;
@@ -454,9 +460,21 @@ __global__ __launch_bounds__(64) void k_reproject_staged(ReprojParams p) {
         if (s == 0) tag0 = j; else if (s == 1) tag1 = j; else if (s == 2) tag2 = j; else tag3 = j;
     };
 
+    // per-row table entries of this tile live in lane (r - rb) and are broadcast with v_readlane
+    // (no scalar-memory round trip inside the row loop); rh <= 64
+    int my_j0 = 0;
+    double my_fy = 0.0;
+    if (rb + lane < re) { my_j0 = p.yj0[p.dst_row0 + rb + lane]; my_fy = p.yfy[p.dst_row0 + rb + lane]; }
+    auto row_j0 = [&](int64_t r) -> int64_t { return (int64_t)__builtin_amdgcn_readlane(my_j0, (int)(r - rb)); };
+    auto row_fy = [&](int64_t r) -> double {
+        int lo = __builtin_amdgcn_readlane(__double2loint(my_fy), (int)(r - rb));
+        int hi = __builtin_amdgcn_readlane(__double2hiint(my_fy), (int)(r - rb));
+        return __hiloint2double(hi, lo);
+    };
+
     double2 ra_[PXL_MAXCH], rb_[PXL_MAXCH];
     {   // prologue: rows of the first output row
-        int64_t j0 = p.yj0[p.dst_row0 + rb];
+        int64_t j0 = row_j0(rb);
         load_row_regs<VEC>(p, splane, j0, cbase0, lane, ra_);
         load_row_regs<VEC>(p, splane, j0 + 1, cbase0, lane, rb_);
         store_row_lds(p, lds + (j0 & 3) * p.seg, lane, ra_);
@@ -466,14 +484,14 @@ __global__ __launch_bounds__(64) void k_reproject_staged(ReprojParams p) {
     }
 
     for (int64_t r = rb; r < re; ++r) {
-        const int64_t j0 = p.yj0[p.dst_row0 + r];
-        const double fy = p.yfy[p.dst_row0 + r];
+        const int64_t j0 = row_j0(r);
+        const double fy = row_fy(r);
 
         // prefetch the rows output row r+1 needs and the ring lacks (global -> registers)
         bool needA = false, needB = false;
         int64_t jn = 0;
         if (r + 1 < re) {
-            jn = p.yj0[p.dst_row0 + r + 1];
+            jn = row_j0(r + 1);
             needA = !resident(jn);
             needB = !resident(jn + 1);
             if (needA) load_row_regs<VEC>(p, splane, jn, cbase0, lane, ra_);
@@ -497,7 +515,8 @@ __global__ __launch_bounds__(64) void k_reproject_staged(ReprojParams p) {
             }
             int64_t col = c0 + q * 128 + 2 * lane;
             double* o = dplane + r * p.nxo + col;
-            if (vec_store) { if (act[q][0]) *reinterpret_cast<double2*>(o) = make_double2(v[0], v[1]); }
+            if (p.flags & 2) { if (v[0] == 1.2345e300) o[0] = v[1]; }       // diagnostics: keep v live, never store
+            else if (vec_store) { if (act[q][0]) *reinterpret_cast<double2*>(o) = make_double2(v[0], v[1]); }
             else { if (act[q][0]) o[0] = v[0]; if (act[q][1]) o[1] = v[1]; }
         }
 
@@ -509,6 +528,9 @@ __global__ __launch_bounds__(64) void k_reproject_staged(ReprojParams p) {
         }
     }
 }
+
+
+#include "pxl_reproject_dma.h"
 
 // ---- scattered sample: one lane per point, fused sky2pix!(safe=true) + 2x2 gather.
 __global__ __launch_bounds__(256) void k_sample_bilinear(Sky2Pix s, const double* __restrict__ src, int64_t nx,
@@ -580,10 +602,16 @@ struct pxl_reproject_plan {
     int32_t* h_yj0;
     // launch configuration
     int variant;       // 0 auto, 1 gather, 2 staged
-    int pairs;         // 1 or 2
+    int pairs;         // lane width of the register-staged kernel: 1 or 2 (x2 output columns per lane)
+    int pairs_dma;     // lane width of the LDS-DMA kernel: 1, 2 or 4
+    int seg_dma;
+    int dypos;
     int rh;
     int seg;
     int dxpos;
+    int flags;
+    int ns, pf;
+    double* zero_page;
     bool staged_ok;
     bool vec_load;
     bool tables_built;
@@ -774,10 +802,14 @@ int pxl_reproject_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[
     size_t off_yfy = off_xfx + ((nxo * 8 + 15) & ~(size_t)15);
     size_t off_xi0 = off_yfy + ((nyo * 8 + 15) & ~(size_t)15);
     size_t off_yj0 = off_xi0 + ((nxo * 4 + 15) & ~(size_t)15);
-    size_t total = off_yj0 + ((nyo * 4 + 15) & ~(size_t)15);
+    size_t off_zero = off_yj0 + ((nyo * 4 + 15) & ~(size_t)15);
+    size_t total = off_zero + 64;
     e = hipMalloc(&pl->table_mem, total);
     if (e != hipSuccess) { delete pl; return fail(PXL_ENOMEM, "plan_create: hipMalloc(%zu): %s", total, hipGetErrorString(e)); }
     char* base = (char*)pl->table_mem;
+    e = hipMemset(base + off_zero, 0, 64);
+    if (e != hipSuccess) { (void)hipFree(pl->table_mem); delete pl; return fail(PXL_EHIP, "plan_create: hipMemset: %s", hipGetErrorString(e)); }
+    pl->zero_page = (double*)(base + off_zero);
     pl->xfx = (double*)(base + off_xfx); pl->yfy = (double*)(base + off_yfy);
     pl->xi0 = (int32_t*)(base + off_xi0); pl->yj0 = (int32_t*)(base + off_yj0);
 
@@ -794,10 +826,18 @@ int pxl_reproject_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[
     // ---- choose the launch configuration from the RA scale (source columns per output column)
     double sx = fabs((pl->wout.cdelt[0] * pl->wout.unit) / (pl->win.cdelt[0] * pl->win.unit));
     pl->dxpos = ((pl->wout.cdelt[0] * pl->wout.unit) / (pl->win.cdelt[0] * pl->win.unit)) > 0 ? 1 : 0;
-    pl->pairs = env_int("PXL_REPROJECT_PAIRS", 2);
-    if (pl->pairs != 1 && pl->pairs != 2) pl->pairs = 2;
-    pl->rh = env_int("PXL_REPROJECT_RH", 64);
+    pl->dypos = ((pl->wout.cdelt[1] * pl->wout.unit) / (pl->win.cdelt[1] * pl->win.unit)) > 0 ? 1 : 0;
+    double sy = fabs((pl->wout.cdelt[1] * pl->wout.unit) / (pl->win.cdelt[1] * pl->win.unit));
+    pl->rh = env_int("PXL_REPROJECT_RH", 32);
     if (pl->rh < 1) pl->rh = 1;
+    if (pl->rh > 64) pl->rh = 64;          // one lane per tile row holds the row-table entry
+    pl->flags = env_int("PXL_REPROJECT_FLAGS", 0);
+    pl->ns = env_int("PXL_REPROJECT_NS", 8);
+    if (pl->ns < 4) pl->ns = 4;
+    while (pl->ns & (pl->ns - 1)) pl->ns &= pl->ns - 1;       // power of two
+    if (pl->ns > 64) pl->ns = 64;
+    pl->pf = env_int("PXL_REPROJECT_PF", 3);
+    if (pl->pf < 0) pl->pf = 0;
     const int max_seg = PXL_MAXCH * 128;
     auto seg_for = [&](int pairs) -> int64_t {
         // footprint of TW columns: ceil(TW*sx) cells + 2 (tap +1, rounding) + 1 (even alignment) + 2 slack
@@ -805,9 +845,19 @@ int pxl_reproject_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[
         int64_t s = (int64_t)span;
         return (s + 1) & ~(int64_t)1;
     };
+    int want = env_int("PXL_REPROJECT_PAIRS", 2);
+    if (want != 1 && want != 2 && want != 4) want = 2;
+    // LDS-DMA kernel: widest lane width whose slot fits
+    pl->pairs_dma = want;
+    while (pl->pairs_dma > 1 && seg_for(pl->pairs_dma) > max_seg) pl->pairs_dma >>= 1;
+    pl->seg_dma = (int)std::min<int64_t>(seg_for(pl->pairs_dma), max_seg);
+    // register-staged kernel: 1 or 2
+    pl->pairs = want > 2 ? 2 : want;
+    if (seg_for(pl->pairs) > max_seg && pl->pairs == 2) pl->pairs = 1;
     int64_t seg = seg_for(pl->pairs);
-    if (seg > max_seg && pl->pairs == 2) { pl->pairs = 1; seg = seg_for(1); }
-    pl->staged_ok = (seg <= max_seg) && !(pl->periodic && seg > pl->nx);   // slot never laps the ring of pixels
+    // stageable: the slot fits, never laps the ring of pixels, and rows are not skipped wholesale
+    auto stageable = [&](int64_t sg) { return (sg <= max_seg) && !(pl->periodic && sg > pl->nx) && sy <= 3.0; };
+    pl->staged_ok = stageable(seg) && stageable(seg_for(pl->pairs_dma));
     pl->seg = (int)(seg <= max_seg ? seg : max_seg);
     pl->vec_load = (pl->nx % 2 == 0);
     *out = pl;
@@ -864,17 +914,26 @@ int pxl_reproject_execute_rows(pxl_reproject_plan* pl, const double* src, double
         return check_launch("k_reproject_gather");
     }
 
-    const int TW = 128 * pl->pairs;
-    p.rh = pl->rh; p.seg = pl->seg; p.dxpos = pl->dxpos;
+    const bool vec = pl->vec_load && (((uintptr_t)src & 15) == 0);
+    const bool use_dma = vec && pl->variant != 2;
+    const int pairs = use_dma ? pl->pairs_dma : pl->pairs;
+    const int TW = 128 * pairs;
+    p.rh = pl->rh; p.seg = use_dma ? pl->seg_dma : pl->seg; p.dxpos = pl->dxpos; p.dypos = pl->dypos; p.flags = pl->flags;
     p.ntx = (int32_t)((pl->nxo + TW - 1) / TW);
     p.nty = (int32_t)((nr + pl->rh - 1) / pl->rh);
     p.ntiles = (int64_t)p.ntx * p.nty * pl->nc;
     p.tiles_per_xcd = (p.ntiles + 7) / 8;
     int64_t nblocks = p.tiles_per_xcd * 8;
     if (nblocks > 0x7fffffffLL) return fail(PXL_EINVAL, "execute: too many tiles (%lld)", (long long)nblocks);
-    size_t lds_bytes = (size_t)PXL_NS * (size_t)pl->seg * sizeof(double);
-    const bool vec = pl->vec_load && (((uintptr_t)src & 15) == 0);
     dim3 grid((unsigned)nblocks), block(64);
+    if (use_dma) {
+        // LDS-DMA fast path; shrink the ring if it would not fit a CU's LDS comfortably
+        p.ns = pl->ns; p.pf = pl->pf; p.zero_page = pl->zero_page;
+        while ((size_t)p.ns * p.seg * 8 > 40 * 1024 && p.ns > 4) p.ns >>= 1;
+        size_t dma_lds = (size_t)p.ns * (size_t)p.seg * sizeof(double);
+        return launch_reproject_dma(pairs, (p.seg + 127) / 128, grid, dma_lds, (hipStream_t)stream, p);
+    }
+    size_t lds_bytes = (size_t)PXL_NS * (size_t)pl->seg * sizeof(double);
     if (pl->pairs == 2) {
         if (vec) hipLaunchKernelGGL((k_reproject_staged<2, true>), grid, block, lds_bytes, st, p);
         else     hipLaunchKernelGGL((k_reproject_staged<2, false>), grid, block, lds_bytes, st, p);

@@ -1,0 +1,242 @@
+// pxl_reproject_dma.h -- the LDS-DMA reprojection kernel (fast path of R1); included by pxl_kernels.hip.
+//
+// ONE WAVEFRONT PER OUTPUT TILE.  A tile is TW = 128*PAIRS output columns x rh output rows of one
+// component plane; the wave marches down the tile's rows.  Source rows go HBM -> LDS directly with
+// `global_load_lds_dwordx4` (16 B per lane, 1 KiB per instruction, no VGPR staging) into a ring of
+// `ns` LDS slots, several rows ahead of the row being interpolated: the ring is the in-flight buffer
+// that hides HBM latency, since each wave's loads are otherwise a dependent chain.
+//
+// The kernel requires the tile's source-row sequence to be monotone (it is, for an affine CAR -> CAR
+// row map, except across a y-rewind jump); rows are then requested strictly in order, one ring slot per
+// row (slot = t & (ns-1), t = +-row), and all bookkeeping is wave-uniform scalar arithmetic:
+//   treq        highest t requested so far
+//   need        t0 + 1, the farther of the two rows the current output row reads
+//   s_waitcnt vmcnt((treq - need) * NCH)   -- exactly the DMA instructions issued after row `need`'s
+// (stores also count in vmcnt, in issue order, so ignoring them only makes the wait stricter).
+// Tiles that are not monotone, or whose columns do not fit the slot, take the direct-tap fallback.
+//
+// RA seam: slot element k holds source column (cbase0 + k) mod nx, resolved in the per-lane source
+// address of the DMA, so the interpolation never sees the seam.  Columns outside a non-periodic map and
+// rows outside the map/window read a 16-byte zero page instead (every lane always issues, LDS needs no
+// zero fill, and the DMA count stays exact).
+#pragma once
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// wait until the DMA of the row that is `k` rows older than the newest requested row has landed
+template <int NCH>
+__device__ __forceinline__ void wait_rows(int k) {
+    constexpr int C = (63 / NCH);          // vmcnt saturates at 63
+    if (k > C) k = C;
+    switch (k) {
+        case 0: wait_vm<0>(); break;
+        case 1: wait_vm<(1 * NCH > 63 ? 63 : 1 * NCH)>(); break;
+        case 2: wait_vm<(2 * NCH > 63 ? 63 : 2 * NCH)>(); break;
+        case 3: wait_vm<(3 * NCH > 63 ? 63 : 3 * NCH)>(); break;
+        case 4: wait_vm<(4 * NCH > 63 ? 63 : 4 * NCH)>(); break;
+        case 5: wait_vm<(5 * NCH > 63 ? 63 : 5 * NCH)>(); break;
+        case 6: wait_vm<(6 * NCH > 63 ? 63 : 6 * NCH)>(); break;
+        case 7: wait_vm<(7 * NCH > 63 ? 63 : 7 * NCH)>(); break;
+        case 8: wait_vm<(8 * NCH > 63 ? 63 : 8 * NCH)>(); break;
+        case 9: wait_vm<(9 * NCH > 63 ? 63 : 9 * NCH)>(); break;
+        case 10: wait_vm<(10 * NCH > 63 ? 63 : 10 * NCH)>(); break;
+        case 11: wait_vm<(11 * NCH > 63 ? 63 : 11 * NCH)>(); break;
+        case 12: wait_vm<(12 * NCH > 63 ? 63 : 12 * NCH)>(); break;
+        case 13: wait_vm<(13 * NCH > 63 ? 63 : 13 * NCH)>(); break;
+        case 14: wait_vm<(14 * NCH > 63 ? 63 : 14 * NCH)>(); break;
+        default: wait_vm<(15 * NCH > 63 ? 63 : 15 * NCH)>(); break;     // k >= 15: rounding down is safe
+    }
+}
+
+// One 1-KiB LDS-DMA: lane l copies 16 B from (sbase + voff[l]) to LDS[lds_byte_addr + 16*l].
+// M0 carries the LDS destination and is written in the same statement that uses it.
+__device__ __forceinline__ void glds16_saddr(const void* sbase, uint32_t voff, uint32_t lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %0"
+                 :: "s"(sbase), "v"(voff), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ void glds16_vaddr(const void* gsrc, uint32_t lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+
+template <int PAIRS, int NCH>
+__global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // ns * seg doubles
+    const int lane = threadIdx.x;
+    constexpr int TW = 128 * PAIRS;
+
+    // XCD-aware decode: blocks b and b+8 share an XCD; give each XCD a contiguous run of tiles so that
+    // RA-neighbouring tiles (shared 128-B lines at the edges, same source rows) meet in one L2.
+    const int64_t b = blockIdx.x;
+    const int64_t t = (p.flags & 4) ? b : (b & 7) * p.tiles_per_xcd + (b >> 3);
+    if (t >= p.ntiles) return;
+    const int tx = (int)(t % p.ntx);
+    const int64_t trest = t / p.ntx;
+    const int ty = (int)(trest % p.nty);
+    const int c = (int)(trest / p.nty);
+
+    const double* splane = p.src + (int64_t)c * p.nx * p.src_nrows;
+    double* dplane = p.dst + (int64_t)c * p.nxo * p.dst_nrows;
+
+    const int64_t c0 = (int64_t)tx * TW;
+    const int64_t clast = (c0 + TW < p.nxo ? c0 + TW : p.nxo) - 1;
+    const int64_t rb = p.r0 + (int64_t)ty * p.rh;
+    const int64_t re = (rb + p.rh < p.r0 + p.nr) ? rb + p.rh : p.r0 + p.nr;
+    const int nrows = (int)(re - rb);
+
+    // ---- per-lane column setup (constant over the tile)
+    const int64_t a = p.dxpos ? p.xi0[c0] : p.xi0[clast];      // 1-based source cell at the tile's low end
+    const int64_t ua = a - 1;
+    const int64_t cbase0 = ua & ~(int64_t)1;                   // even 0-based source column at slot index 0
+    int dloc[PAIRS][2];
+    double fx[PAIRS][2];
+    bool act[PAIRS][2];
+    bool fits = true;
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            int64_t col = c0 + q * 128 + 2 * lane + e;
+            act[q][e] = col < p.nxo;
+            int64_t i0 = act[q][e] ? p.xi0[col] : a;
+            fx[q][e] = act[q][e] ? p.xfx[col] : 0.0;
+            int64_t d = i0 - a;
+            if (p.periodic) { d %= p.nx; if (d < 0) d += p.nx; }
+            d += ua - cbase0;
+            if (d < 0 || d + 1 >= p.seg) fits = false;
+            dloc[q][e] = (int)d;
+        }
+    }
+
+    // ---- row table of this tile: lane l holds output row rb + l; broadcast with v_readlane
+    int my_j0 = 0;
+    double my_fy = 0.0;
+    if (lane < nrows) { my_j0 = p.yj0[p.dst_row0 + rb + lane]; my_fy = p.yfy[p.dst_row0 + rb + lane]; }
+    const int dir = p.dypos ? 1 : -1;
+    const int my_t0 = p.dypos ? my_j0 : -(my_j0 + 1);          // rows needed: t0, t0+1 in t = dir*row space
+    {
+        int nxt = __shfl_down(my_t0, 1, 64);
+        bool mono = (lane + 1 >= nrows) || (nxt >= my_t0);
+        if (!mono) fits = false;
+    }
+
+    if (!__all(fits)) {
+        // wave-uniform fallback: direct taps (rewind discontinuity inside the tile)
+        SrcView m{splane, p.nx, p.ny, p.src_row0, p.src_nrows, p.periodic};
+        for (int64_t r = rb; r < re; ++r) {
+            int64_t j0 = p.yj0[p.dst_row0 + r];
+            double fy = p.yfy[p.dst_row0 + r];
+#pragma unroll
+            for (int q = 0; q < PAIRS; ++q)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    int64_t col = c0 + q * 128 + 2 * lane + e;
+                    if (act[q][e]) dplane[r * p.nxo + col] = bilerp_cells(m, p.xi0[col], fx[q][e], j0, fy);
+                }
+        }
+        return;
+    }
+
+    // ---- per-lane source byte offsets of each 1-KiB chunk within a source row (constant over the tile);
+    //      0xFFFFFFFF marks a column outside a non-periodic map
+    uint32_t voff[NCH];
+    bool chunk_in[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        int64_t u = cbase0 + ch * 128 + 2 * lane;
+        bool ok = true;
+        if (p.periodic) { u %= p.nx; if (u < 0) u += p.nx; }
+        else ok = (u >= 0) && (u < p.nx);
+        voff[ch] = ok ? (uint32_t)(u * 8) : 0xFFFFFFFFu;
+        chunk_in[ch] = (ch * 128 + 2 * lane) < p.seg;           // tail chunk: lanes past the slot end stay out
+    }
+
+    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+    const uint32_t slot_bytes = (uint32_t)p.seg * 8u;
+    const int ns_mask = p.ns - 1;
+    const bool skip_loads = (p.flags & 1) != 0;
+
+    auto issue_row = [&](int tt) {      // request source row j = dir * tt into slot tt & ns_mask
+        const int j = dir * tt;
+        const int64_t jr = (int64_t)j - 1 - p.src_row0;
+        const bool row_ok = (j >= 1) && (j <= p.ny) && (jr >= 0) && (jr < p.src_nrows) && !skip_loads;
+        const uint32_t slot_addr = lds_base + (uint32_t)(tt & ns_mask) * slot_bytes;
+        if (p.periodic) {
+            // every lane has a valid column: SGPR row base + 32-bit per-lane offset
+            const double* rowp = row_ok ? splane + jr * p.nx : p.zero_page;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const uint32_t off = row_ok ? voff[ch] : 0u;
+                if ((ch + 1) * 128 <= p.seg) glds16_saddr(rowp, off, slot_addr + ch * 1024u);
+                else if (chunk_in[ch]) glds16_saddr(rowp, off, slot_addr + ch * 1024u);   // lane 0 is always in
+            }
+        } else {
+            const double* rowp = splane + (row_ok ? jr : 0) * p.nx;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const void* g = (row_ok && voff[ch] != 0xFFFFFFFFu)
+                                    ? (const void*)((const char*)rowp + voff[ch]) : (const void*)p.zero_page;
+                if ((ch + 1) * 128 <= p.seg) glds16_vaddr(g, slot_addr + ch * 1024u);
+                else if (chunk_in[ch]) glds16_vaddr(g, slot_addr + ch * 1024u);
+            }
+        }
+    };
+
+    const bool vec_store = ((p.nxo & 1) == 0) && (((uintptr_t)p.dst & 15) == 0);
+    double* orow = dplane + rb * p.nxo + c0 + 2 * lane;        // this lane's first output pair in row rb
+
+    int treq = __builtin_amdgcn_readlane(my_t0, 0) - 1;        // nothing requested yet
+    for (int rr = 0; rr < nrows; ++rr) {
+        const int t0 = __builtin_amdgcn_readlane(my_t0, rr);
+        const double fy = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_fy), rr),
+                                           __builtin_amdgcn_readlane(__double2loint(my_fy), rr));
+        // top up the ring: rows up to the farther row of output row rr + pf, but never onto a live slot
+        {
+            const int ra = (rr + p.pf < nrows) ? rr + p.pf : nrows - 1;
+            int tmax = __builtin_amdgcn_readlane(my_t0, ra) + 1;
+            const int tlim = t0 + p.ns - 1;
+            if (tmax > tlim) tmax = tlim;
+            while (treq < tmax) { ++treq; issue_row(treq); }
+        }
+        wait_rows<NCH>(treq - (t0 + 1));
+
+        const int st = (p.dypos ? t0 : t0 + 1) & ns_mask;      // slot of source row j0 (top)
+        const int sb = (p.dypos ? t0 + 1 : t0) & ns_mask;      // slot of source row j0 + 1 (bottom)
+        const double* T = lds + st * p.seg;
+        const double* B = lds + sb * p.seg;
+        const double wy = 1 - fy;
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) {
+            double v[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int d = dloc[q][e];
+                const double wx = 1 - fx[q][e];
+                const double top = wx * T[d] + fx[q][e] * T[d + 1];
+                const double bot = wx * B[d] + fx[q][e] * B[d + 1];
+                v[e] = wy * top + fy * bot;
+            }
+            double* o = orow + q * 128;
+            if (p.flags & 2) { if (v[0] == 1.2345e300) o[0] = v[1]; }       // diagnostics: keep v live, never store
+            else if (vec_store) { if (act[q][0]) *reinterpret_cast<double2*>(o) = make_double2(v[0], v[1]); }
+            else { if (act[q][0]) o[0] = v[0]; if (act[q][1]) o[1] = v[1]; }
+        }
+        orow += p.nxo;
+        // the LDS reads above have returned (their values were consumed); make that explicit before a
+        // later DMA may overwrite their slots
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+static int launch_reproject_dma(int pairs, int nch, dim3 grid, size_t lds_bytes, hipStream_t st, const ReprojParams& p) {
+#define PXL_DMA_CASE(P, N) \
+    if (pairs == P && nch == N) { hipLaunchKernelGGL((k_reproject_dma<P, N>), grid, dim3(64), lds_bytes, st, p); return check_launch("k_reproject_dma"); }
+    PXL_DMA_CASE(1, 1) PXL_DMA_CASE(1, 2) PXL_DMA_CASE(1, 3) PXL_DMA_CASE(1, 4) PXL_DMA_CASE(1, 5)
+    PXL_DMA_CASE(2, 1) PXL_DMA_CASE(2, 2) PXL_DMA_CASE(2, 3) PXL_DMA_CASE(2, 4) PXL_DMA_CASE(2, 5)
+    PXL_DMA_CASE(4, 2) PXL_DMA_CASE(4, 3) PXL_DMA_CASE(4, 4) PXL_DMA_CASE(4, 5)
+#undef PXL_DMA_CASE
+    return fail(PXL_EINVAL, "reproject: no LDS-DMA kernel for pairs=%d nch=%d", pairs, nch);
+}

@@ -245,7 +245,7 @@ def reproject_cases(pj):
 
 
 @pytest.mark.parametrize("ncomp", [1, 3])
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_reproject_vs_oracle(pj, O, dev, ncomp, variant):
     rng = np.random.default_rng(42)
     for name, ((shape_in, wcs_in), (shape_out, wcs_out)) in reproject_cases(pj).items():
@@ -278,7 +278,7 @@ def test_reproject_enmap_api(pj, O, dev):
 @pytest.mark.parametrize("rh", [1, 5, 64])
 def test_reproject_tile_heights(pj, O, dev, rh, monkeypatch):
     """Different tile heights / lane widths walk the LDS ring differently; results must not change."""
-    for pairs in (1, 2):
+    for pairs in (1, 2, 4):
         monkeypatch.setenv("PXL_REPROJECT_RH", str(rh))
         monkeypatch.setenv("PXL_REPROJECT_PAIRS", str(pairs))
         rng = np.random.default_rng(6)

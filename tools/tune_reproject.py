@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of k_reproject_staged launch configurations (one process, N variants x M
+rounds, median and min reported -- cdna_hip_programming.md rule 24).
+
+    python tools/tune_reproject.py --workload cfg4 --rounds 7 "rh=64,pairs=2" "rh=16,pairs=1" "rh=64,flags=1"
+
+Variant keys map to the PXL_REPROJECT_* environment knobs read at plan creation.
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import pixell_jl_amd as pj  # noqa: E402
+
+KEYS = {"rh": "PXL_REPROJECT_RH", "pairs": "PXL_REPROJECT_PAIRS", "flags": "PXL_REPROJECT_FLAGS",
+        "variant": "PXL_REPROJECT_VARIANT", "pf": "PXL_REPROJECT_PF", "ns": "PXL_REPROJECT_NS",
+        "wg": "PXL_REPROJECT_WG", "order": "PXL_REPROJECT_ORDER"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="cfg4")
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("variants", nargs="+")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    shape_in, wcs_in, shape_out, wcs_out, desc = bench.workload_geometry(args.workload)
+    nx, ny, nc = shape_in
+    nxo, nyo = shape_out
+    src = torch.empty((nc, ny, nx), dtype=torch.float64, device=dev)
+    dst = torch.empty((nc, nyo, nxo), dtype=torch.float64, device=dev)
+    pj.fill_random_(src, 1234)
+    plans = []
+    for v in args.variants:
+        for k in KEYS.values():
+            os.environ.pop(k, None)
+        for kv in v.split(","):
+            if kv:
+                k, val = kv.split("=")
+                os.environ[KEYS[k]] = val
+        plans.append(pj.ReprojectPlan(shape_in, wcs_in, shape_out, wcs_out, device=dev))
+    for pl in plans:
+        pl.build_tables()
+        pl.execute_rows(src, dst, 0, nyo)       # warm-up
+    torch.cuda.synchronize()
+    times = [[] for _ in plans]
+    for _ in range(args.rounds):
+        for i, pl in enumerate(plans):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            pl.execute_rows(src, dst, 0, nyo)
+            e1.record()
+            torch.cuda.synchronize()
+            times[i].append(e0.elapsed_time(e1))
+    alg = 8.0 * nc * (nx * ny + nxo * nyo)
+    print("workload:", desc)
+    for v, t in zip(args.variants, times):
+        t = sorted(t)
+        med, mn = t[len(t) // 2], t[0]
+        print("%-40s median %8.4f ms  min %8.4f ms  -> %7.1f GB/s (%.1f%% of 8 TB/s)" % (
+            v, med, mn, alg / med / 1e6, alg / med / 1e6 / 80.0))
+
+
+if __name__ == "__main__":
+    main()
