@@ -104,10 +104,12 @@ def cpu_baseline_reproject(shape_in, wcs_in, shape_out, wcs_out, budget_s=12.0):
 
 
 def load_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic_<workload>.json, produced by tools/make_traffic.py); None if not collected."""
     p = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
     if os.path.exists(p):
         with open(p) as f:
-            return json.load(f)
+            return json.load(f)["hbm_bytes_per_launch"]
     return None
 
 
@@ -210,7 +212,7 @@ def bench_reproject(args, rank, world, dev):
                        world, max([hi - lo for _, lo, hi in sh.recvs], default=0)),
                    "halo_bytes_per_rank": sh.halo_bytes(),
                    "bytes_per_output_value": round(8.0 * (nx * ny + nxo * nyo) / (nxo * nyo), 3)},
-        "roofline": {"bound": "hbm", "kernel": "k_reproject_staged",
+        "roofline": {"bound": "hbm", "kernel": "k_reproject_dma",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic,
