@@ -1,0 +1,195 @@
+"""Host-side mirror of the reference interface (geometry constructors, slicing, scalar evaluators, Enmap
+container): against the reference literals and, bit for bit, against the C oracle.  CPU only."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import ARCMIN, DEG, bits_equal, isapprox
+
+
+def test_fullsky_geometry_literals(pj, literals):
+    for lit in literals["fullsky_geometry"]:
+        shape, w = pj.fullsky_geometry(eval(lit["res_expr"]) * DEG)
+        assert list(shape) == lit["shape"]
+        for k in ("cdelt", "crpix", "crval"):
+            if k in lit:
+                assert isapprox(getattr(w, k), lit[k])
+    shape, w = pj.fullsky_geometry(5 * DEG, dims=(3,))
+    assert shape == (72, 37, 3)                                    # test_geometry.jl:17-18
+    with pytest.raises(AssertionError):
+        pj.fullsky_geometry(0.0123)
+
+
+def test_geometry_matches_oracle_bits(pj, O, literals):
+    for lit in literals["geometry"]:
+        b = lit["box_deg"]
+        box = [[b[0][0] * DEG, b[0][1] * DEG], [b[1][0] * DEG, b[1][1] * DEG]]
+        shape, w = pj.geometry(box, lit["res_arcmin"] * ARCMIN)
+        oshape, ow = O.geometry((box[0][0], box[1][0]), (box[0][1], box[1][1]), lit["res_arcmin"] * ARCMIN)
+        assert shape == oshape == tuple(lit["shape"])
+        assert w.cdelt == tuple(ow.cdelt) and w.crpix == tuple(ow.crpix) and w.crval == tuple(ow.crval)
+    for res in (1 * DEG, 1 / 60 * DEG, 2 * math.pi / 43200, 2 * math.pi / 1024):
+        shape, w = pj.fullsky_geometry(res)
+        oshape, ow = O.fullsky_geometry(res)
+        assert shape == oshape
+        assert w.cdelt == tuple(ow.cdelt) and w.crpix == tuple(ow.crpix) and w.crval == tuple(ow.crval)
+        assert w.unit == ow.unit
+
+
+def test_benchmark_geometries(pj):
+    """The natural Clenshaw-Curtis shapes of the BASELINE.json configs ('Config geometries')."""
+    for nx, ny in ((1024, 513), (4096, 2049), (21600, 10801), (43200, 21601)):
+        shape, w = pj.fullsky_geometry(2 * math.pi / nx)
+        assert shape == (nx, ny)
+        assert pj.is_periodic(w, nx)
+    shape, w = pj.fullsky_geometry(2 * math.pi / 43200)
+    assert isapprox(w.cdelt, [-0.008333333333333333, 0.008333333333333333])
+    assert w.crpix == (21600.5, 10801.0)
+    assert isapprox(w.crval, [0.004166666666666667, 0.0])
+
+
+def test_slice_geometry_literals(pj, literals):
+    shape0, w0 = pj.fullsky_geometry(1 * DEG)
+    for lit in literals["slice_geometry_1deg"]:
+        (fx, sx, ex), (fy, sy, ey) = lit["sel"]
+        shape, w = pj.slice_geometry(shape0, w0, (fx, sx, ex), (fy, sy, ey))
+        assert list(shape) == lit["shape"], lit["src"]
+        assert isapprox(w.cdelt, lit["cdelt"]) and isapprox(w.crpix, lit["crpix"]) and isapprox(w.crval, lit["crval"])
+    # dec-strip shard descriptor: crpix'[2] = crpix[2] - (j0 - 1)   
+    shape, w = pj.slice_geometry(shape0, w0, None, (41, 90))
+    assert shape == (360, 50) and w.crpix == (w0.crpix[0], w0.crpix[1] - 40) and w.cdelt == w0.cdelt
+
+
+def test_jlrange_normalisation(pj):
+    assert pj.JlRange(3, 24, 5).last == 23 and pj.JlRange(3, 24, 5).length == 5
+    assert pj.JlRange(39, 2, -3).last == 3 and pj.JlRange(39, 2, -3).length == 13
+    assert pj.JlRange(23, 6, -4).last == 7
+    assert pj.JlRange(1, 28, 3).last == 28
+    a = np.arange(1, 41)
+    assert list(a[pj.JlRange(39, 2, -3).to_slice()]) == list(range(39, 2, -3))
+    assert list(a[pj.JlRange(3, 1, -1).to_slice()]) == [3, 2, 1]
+
+
+def test_scalar_evaluators_match_oracle_bits(pj, O):
+    rng = np.random.default_rng(0)
+    geoms = [pj.fullsky_geometry(1 * DEG), pj.geometry([[10 * DEG, -10 * DEG], [-5 * DEG, 5 * DEG]], 1 * DEG),
+             pj.fullsky_geometry(2 * math.pi / 43200)]
+    for shape, w in geoms:
+        i = rng.uniform(-100, shape[0] + 100, 300)
+        j = rng.uniform(-100, shape[1] + 100, 300)
+        for safe in (True, False):
+            host = np.array([pj.pix2sky((shape, w), float(a), float(b), safe=safe) for a, b in zip(i, j)])
+            ra, dec = O.pix2sky_soa(w, i, j, safe=safe)
+            assert bits_equal(host[:, 0], ra) and bits_equal(host[:, 1], dec)
+            ra_in = rng.uniform(-30, 30, 300)
+            dec_in = rng.uniform(-8, 8, 300)
+            host = np.array([pj.sky2pix((shape, w), float(a), float(b), safe=safe) for a, b in zip(ra_in, dec_in)])
+            x, y = O.sky2pix_soa(w, shape, ra_in, dec_in, safe=safe, form=O.FORM_DIV)
+            assert bits_equal(host[:, 0], x) and bits_equal(host[:, 1], y)
+
+
+def test_scalar_literals(pj, literals):
+    shape, w = pj.fullsky_geometry(1 * DEG)
+    m = (shape, w)
+    for lit in literals["pix2sky_1deg"]:
+        assert isapprox(pj.pix2sky(m, lit["pix"]), lit["sky"])            # 2-vector method
+    for lit in literals["roundtrip_1deg"]:
+        sky = pj.pix2sky(m, lit["pix"])
+        add = [k * math.pi for k in lit.get("add_pi", [0, 0])]
+        assert isapprox(pj.sky2pix(m, [sky[0] + add[0], sky[1] + add[1]]), lit["pix"])
+    for lit in literals["sky2pix_1deg"]:
+        assert isapprox(pj.sky2pix(m, lit["sky_deg"][0] * DEG, lit["sky_deg"][1] * DEG), lit["pix"])
+    lit = literals["wrap_box_1deg"]
+    b = lit["box_deg"]
+    bm = pj.geometry([[b[0][0] * DEG, b[0][1] * DEG], [b[1][0] * DEG, b[1][1] * DEG]], lit["res_deg"] * DEG)
+    assert isapprox([pj.sky2pix(bm, ra * DEG, 0.0, safe=True)[0] for ra in lit["ra_deg"]], lit["pix_ra"])
+    with pytest.raises(AssertionError):
+        pj.sky2pix(m, [1.0, 2.0, 3.0])
+
+
+def test_two_vector_pix2sky_ignores_safe_like_the_reference(pj):
+    """car_proj.jl:155-162: the inner scalar call is made without forwarding `safe`, so it always rewinds."""
+    shape, w = pj.fullsky_geometry(1 * DEG)
+    far = [400.0, 5.0]
+    assert pj.pix2sky((shape, w), far, safe=False) == pj.pix2sky((shape, w), far, safe=True)
+    assert pj.pix2sky((shape, w), far[0], far[1], safe=False) != tuple(pj.pix2sky((shape, w), far, safe=False))
+
+
+def test_gnomonic_host(pj, O, literals):
+    g = literals["gnomonic"]
+    w = pj.Gnomonic(g["cdelt"], g["crpix"], g["crval"])
+    shape = tuple(g["shape"])
+    for lit in g["pix2sky"]:
+        assert isapprox(pj.pix2sky((shape, w), float(lit["pix"][0]), float(lit["pix"][1])), lit["sky"])
+    a, d = g["roundtrip_sky"]
+    x, y = pj.sky2pix((shape, w), a, d)
+    ox, oy = O.sky2pix_tan(w, [a], [d])
+    assert abs(x - ox[0]) < 1e-9 and abs(y - oy[0]) < 1e-9
+    a2, d2 = pj.pix2sky((shape, w), x, y)
+    assert abs(a2 - a) < 1e-12 and abs(d2 - d) < 1e-12
+
+
+def test_skyarea_and_bbox(pj, literals):
+    shape, w = pj.fullsky_geometry(1 * DEG)
+    assert math.isclose(pj.skyarea(shape, w), 4 * math.pi, rel_tol=1.5e-8)
+    s2, w2 = pj.slice_geometry(shape, w, (9, -1, 3), (1, 1, 2))
+    assert math.isclose(pj.skyarea(s2, w2), 4.1865652086145036e-05, rel_tol=1.5e-8)
+    bb = pj.SkyBoundingBox.from_corners((0.3, -0.1), (-0.2, 0.4))
+    assert (0.0, 0.0) in bb and (0.31, 0.0) not in bb
+
+
+def test_enmap_container_cpu_tensor(pj, literals):
+    """Container semantics work on any torch tensor (slicing re-derives the WCS; test_enmap.jl:2-65)."""
+    import torch
+    shape0, w0 = pj.fullsky_geometry(1 * DEG)
+    data = torch.arange(shape0[0] * shape0[1], dtype=torch.float64).reshape(shape0[1], shape0[0])
+    m = pj.Enmap(data, w0)
+    assert m.shape == shape0 and m.size() == shape0
+    v = m.view((5, 10), None)
+    assert v.shape == (6, 181) and isapprox(v.wcs.crpix, [176.5, 91.0]) and isapprox(v.wcs.cdelt, [-1.0, 1.0])
+    assert torch.equal(v.data, data[:, 4:10])
+    assert v.data.data_ptr() == data[:, 4:10].data_ptr()                  # a view, not a copy
+    g = m.getindex((1, 12), (181, -1, 1))                                 # backwards slicing
+    assert g.shape == (12, 181) and isapprox(g.wcs.cdelt, [-1.0, -1.0]) and isapprox(g.wcs.crpix, [180.5, 91.0])
+    assert torch.equal(g.data, torch.flip(data[:, 0:12], dims=[0]))
+    g = m.getindex((3, 5, 24), (39, -3, 2))                               # non-unit steps
+    assert g.shape == (5, 13) and isapprox(g.wcs.crpix, [36.1, -16.666666666666668])
+    assert torch.equal(g.data, data[[38 - 3 * k for k in range(13)]][:, [2 + 5 * k for k in range(5)]])
+    assert isinstance(m.view(1, None), torch.Tensor)                      # dropped axis -> plain array
+    c = m.copy()
+    c.data += 1
+    assert not torch.equal(c.data, m.data) and c.wcs == m.wcs
+    assert isinstance(pj.getwcs(3.0), pj.NoWCS)
+
+
+def test_device_ops_refuse_cpu_tensors(pj):
+    """The product path has no CPU fallback: CPU arrays are refused, loudly."""
+    import torch
+    shape, w = pj.fullsky_geometry(1 * DEG)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pj.pix2sky((shape, w), torch.zeros((4, 2), dtype=torch.float64))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pj.sky2pix((shape, w), torch.zeros(4, dtype=torch.float64), torch.zeros(4, dtype=torch.float64))
+    m = pj.Enmap(torch.zeros((shape[1], shape[0]), dtype=torch.float64), w)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pj.sample_bilinear(m, torch.zeros((4, 2), dtype=torch.float64))
+
+
+def test_host_row_cells_match_oracle_tables(pj, O):
+    """The sharding planner's numpy row table is the same arithmetic as the oracle's (and the device's)."""
+    from pixell_jl_amd.sharding import host_row_cells
+    cases = [(pj.fullsky_geometry(2 * math.pi / 500), pj.fullsky_geometry(2 * math.pi / 1000)),
+             (pj.fullsky_geometry(2 * math.pi / 43200), None),
+             (pj.geometry([[10 * DEG, -10 * DEG], [-5 * DEG, 5 * DEG]], 2 * ARCMIN),
+              pj.geometry([[-8 * DEG, 9 * DEG], [4 * DEG, -4 * DEG]], 1.5 * ARCMIN))]
+    for gin, gout in cases:
+        shape_in, w_in = gin
+        if gout is None:
+            shape_out = shape_in
+            w_out = pj.CarClenshawCurtis(w_in.cdelt, (w_in.crpix[0] + 0.5, w_in.crpix[1] + 0.5), w_in.crval)
+        else:
+            shape_out, w_out = gout
+        cells = host_row_cells(shape_in, w_in, shape_out, w_out)
+        _, ys = O.reproject_tables(w_in, shape_in, w_out, shape_out)
+        assert np.array_equal(cells, np.floor(ys).astype(np.int64))
