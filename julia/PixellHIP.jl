@@ -1,0 +1,110 @@
+# PixellHIP.jl -- the reference-side binding: new methods of Pixell's own generic functions for maps whose
+# storage lives in MI355X HBM, each a thin `ccall` into libpixell_hip.so (include/pixell_hip.h).
+#
+# NOT EXERCISED IN THIS REPOSITORY'S CI: Julia is not installed in the build image (see DESIGN.md 1); the
+# executable twin of this file is the Python host package pixell.jl_amd/.  It follows the reference's own FFI
+# style (`ccall((:sym, lib), Cint, (...), ...)` + `GC.@preserve`, src/transforms.jl:185-194) but checks the
+# returned code.  No CUDA.jl / AMDGPU.jl: device memory is a minimal array type over hipMalloc.
+module PixellHIP
+
+using Pixell
+import Pixell: Enmap, AbstractCARWCS, CarClenshawCurtis, getwcs, pix2sky, pix2sky!, sky2pix, sky2pix!, posmap
+
+const libpixell_hip = get(ENV, "PIXELL_HIP_LIB", "libpixell_hip.so")
+const libhip = "libamdhip64.so"
+
+# ---- struct pxl_car_wcs == CarClenshawCurtis{Float64} field for field (car_proj.jl:7-12): pass by Ref
+struct CarWCS
+    cdelt::NTuple{2,Cdouble}
+    crpix::NTuple{2,Cdouble}
+    crval::NTuple{2,Cdouble}
+    unit::Cdouble
+end
+CarWCS(w::AbstractCARWCS) = CarWCS(Float64.(w.cdelt), Float64.(w.crpix), Float64.(w.crval), Float64(w.unit))
+
+function check(rc::Cint)
+    rc == 0 && return nothing
+    buf = Vector{UInt8}(undef, 512)
+    ccall((:pxl_last_error, libpixell_hip), Csize_t, (Ptr{UInt8}, Csize_t), buf, 512)
+    error("libpixell_hip ($rc): " * unsafe_string(pointer(buf)))     # the reference raises exceptions too
+end
+
+# ---- minimal device array (column-major, like Array): the `AA` slot of Enmap{T,N,AA,W} (enmap.jl:10)
+mutable struct HIPArray{T,N} <: AbstractArray{T,N}
+    ptr::Ptr{T}
+    dims::NTuple{N,Int}
+    function HIPArray{T,N}(::UndefInitializer, dims::NTuple{N,Int}) where {T,N}
+        p = Ref{Ptr{Cvoid}}()
+        rc = ccall((:hipMalloc, libhip), Cint, (Ptr{Ptr{Cvoid}}, Csize_t), p, prod(dims) * sizeof(T))
+        rc == 0 || error("hipMalloc failed ($rc)")
+        a = new{T,N}(Ptr{T}(p[]), dims)
+        finalizer(x -> ccall((:hipFree, libhip), Cint, (Ptr{Cvoid},), x.ptr), a)
+    end
+end
+HIPArray{T}(u::UndefInitializer, dims::Int...) where {T} = HIPArray{T,length(dims)}(u, dims)
+Base.size(a::HIPArray) = a.dims
+Base.similar(a::HIPArray{T}, ::Type{S}, dims::Dims) where {T,S} = HIPArray{S,length(dims)}(undef, dims)
+Base.unsafe_convert(::Type{Ptr{T}}, a::HIPArray{T}) where {T} = a.ptr
+Base.getindex(::HIPArray, i...) = error("scalar indexing of device memory: copy to the host with Array(a)")
+function HIPArray(h::Array{T,N}) where {T,N}
+    d = HIPArray{T,N}(undef, size(h))
+    GC.@preserve h ccall((:hipMemcpy, libhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), d.ptr, pointer(h), sizeof(h), 1)
+    d
+end
+function Base.Array(d::HIPArray{T,N}) where {T,N}
+    h = Array{T,N}(undef, d.dims)
+    GC.@preserve h ccall((:hipMemcpy, libhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), pointer(h), d.ptr, sizeof(h), 2)
+    h
+end
+
+const DevCoords = HIPArray{Float64,2}                      # 2xN, interleaved pairs (car_proj.jl:102-107)
+const NULLSTREAM = C_NULL
+
+# ---- pix2sky! / sky2pix! for 2xN device batches: same signatures and `safe` keyword as car_proj.jl:92,165
+function Pixell.pix2sky!(shape, wcs::AbstractCARWCS, pix::DevCoords, sky::DevCoords; safe=true)
+    @assert size(pix) == size(sky) && size(pix, 1) == 2
+    GC.@preserve pix sky check(ccall((:pxl_pix2sky_car_f64, libpixell_hip), Cint,
+        (Ref{CarWCS}, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cvoid}),
+        CarWCS(wcs), size(pix, 2), pix.ptr, sky.ptr, safe ? 2 : 0, NULLSTREAM))   # 2 = PXL_WRAP_UNWIND
+    return sky
+end
+Pixell.pix2sky(shape, wcs::AbstractCARWCS, pix::DevCoords; safe=true) =
+    pix2sky!(shape, wcs, pix, similar(pix); safe=safe)
+
+function Pixell.sky2pix!(shape, wcs::AbstractCARWCS, sky::DevCoords, pix::DevCoords; safe=true)
+    @assert size(pix) == size(sky) && size(sky, 1) == 2
+    shp = Int64[shape[1], shape[2]]
+    GC.@preserve pix sky shp check(ccall((:pxl_sky2pix_car_f64, libpixell_hip), Cint,
+        (Ref{CarWCS}, Ptr{Int64}, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Ptr{Cvoid}),
+        CarWCS(wcs), shp, size(sky, 2), sky.ptr, pix.ptr, safe, 0, NULLSTREAM))    # 0 = PXL_FORM_RECIP
+    return pix
+end
+Pixell.sky2pix(shape, wcs::AbstractCARWCS, sky::DevCoords; safe=true) =
+    sky2pix!(shape, wcs, sky, similar(sky); safe=safe)
+
+# ---- posmap on the device (enmap_ops.jl:190-203): returns two device Enmaps
+function posmap_device(shape::Tuple{Int,Int}, wcs::AbstractCARWCS)
+    ra, dec = HIPArray{Float64}(undef, shape...), HIPArray{Float64}(undef, shape...)
+    shp = Int64[shape...]
+    GC.@preserve ra dec shp check(ccall((:pxl_posmap_car_f64, libpixell_hip), Cint,
+        (Ref{CarWCS}, Ptr{Int64}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cvoid}),
+        CarWCS(wcs), shp, 0, shape[2], ra.ptr, dec.ptr, 1, NULLSTREAM))
+    return Enmap(ra, wcs), Enmap(dec, wcs)
+end
+
+# ---- bilinear reprojection of a device Enmap onto (shape_out, wcs_out): the composite of
+#      posmap(out) o sky2pix(in) o 2x2 gather (not in the reference; SURVEY 8(a) R1)
+function reproject(m::Enmap{Float64,N,<:HIPArray,<:AbstractCARWCS}, shape_out::Tuple{Int,Int},
+                   wcs_out::AbstractCARWCS) where {N}
+    nc = N == 3 ? size(m, 3) : 1
+    out = HIPArray{Float64}(undef, shape_out..., (N == 3 ? (nc,) : ())...)
+    shp_in, shp_out = Int64[size(m, 1), size(m, 2), nc], Int64[shape_out...]
+    src = parent(m)
+    GC.@preserve src out shp_in shp_out check(ccall((:pxl_reproject_car_bilinear_f64, libpixell_hip), Cint,
+        (Ref{CarWCS}, Ptr{Int64}, Ptr{Cdouble}, Ref{CarWCS}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Cvoid}),
+        CarWCS(getwcs(m)), shp_in, src.ptr, CarWCS(wcs_out), shp_out, out.ptr, NULLSTREAM))
+    return Enmap(out, wcs_out)
+end
+
+export HIPArray, posmap_device, reproject
+end # module

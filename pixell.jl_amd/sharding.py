@@ -217,5 +217,9 @@ class DecStripReprojector(DecStripLayout):
             if i_hi < nrows:
                 self.plan.execute_rows(src, dst, i_hi, nrows - i_hi)
         else:
+            if events:
+                events[0].record()
             self.plan.execute_rows(src, dst, 0, nrows)
+            if events:
+                events[1].record()
         return dst

@@ -395,3 +395,69 @@ def test_errors_are_reported_not_swallowed(pj, dev):
         pj.ReprojectPlan(shape, wcs, shape, wcs, dst_rows=(100, 500), device=dev)
     with pytest.raises(AssertionError):                    # car_proj.jl:156
         pj.pix2sky((shape, wcs), [1.0, 2.0, 3.0])
+
+
+# ---- dec-strip sharding on the device (single GPU stands in for every rank; no collective needed) ---
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_dec_strip_plans_on_device(pj, dev, world):
+    """Each rank's window plan (own rows + halo, interior/boundary split) reproduces the full-map launch
+    bit for bit.  Halo rows are copied from the full map here; the exchange itself is covered by the gloo
+    tests (tests/test_sharding_gloo.py) and uses the same DecStripLayout."""
+    (shape_in, wcs_in), (shape_out, wcs_out) = reproject_cases(pj)["same_res_quarter_shift"]
+    nx, ny = shape_in
+    nc = 3
+    g = torch.Generator(device="cpu").manual_seed(3)
+    full_src = torch.randn((nc, ny, nx), dtype=torch.float64, generator=g).to(dev)
+    full_plan = pj.ReprojectPlan((nx, ny, nc), wcs_in, shape_out, wcs_out, device=dev)
+    full_dst = torch.empty(full_plan.dst_tensor_shape(), dtype=torch.float64, device=dev)
+    full_plan.execute(full_src, full_dst)
+    for rank in range(world):
+        L = pj.sharding.DecStripLayout((nx, ny, nc), wcs_in, shape_out, wcs_out, rank, world)
+        plan = pj.ReprojectPlan((nx, ny, nc), wcs_in, shape_out, wcs_out, src_rows=L.src_window,
+                                dst_rows=L.dst_window, device=dev)
+        # the C library's host-side row logic agrees with the Python planner
+        assert plan.src_rows_needed() == L.need[rank]
+        assert plan.rows_covered(*L.own[rank]) == L.interior
+        src = torch.full(L.src_tensor_shape(), float("nan"), dtype=torch.float64, device=dev)
+        src[:, L.own_slice(), :] = full_src[:, L.own[rank][0]:L.own[rank][1], :]
+        dst = torch.full(L.dst_tensor_shape(), float("nan"), dtype=torch.float64, device=dev)
+        plan.build_tables()
+        i_lo, i_hi = L.interior
+        plan.execute_rows(src, dst, i_lo, i_hi - i_lo)                 # before the halo "arrives"
+        for _, lo, hi in L.recvs:
+            src[:, lo - L.buf_lo:hi - L.buf_lo, :] = full_src[:, lo:hi, :]
+        if i_lo > 0:
+            plan.execute_rows(src, dst, 0, i_lo)
+        if i_hi < L.dst_window[1]:
+            plan.execute_rows(src, dst, i_hi, L.dst_window[1] - i_hi)
+        lo, n = L.dst_window
+        assert torch.equal(dst, full_dst[:, lo:lo + n, :]), (world, rank)
+
+
+def test_dec_strip_reprojector_world1(pj, dev):
+    (shape_in, wcs_in), (shape_out, wcs_out) = reproject_cases(pj)["refine2x_to_1000"]
+    sh = pj.DecStripReprojector(shape_in, wcs_in, shape_out, wcs_out, 0, 1, dev)
+    src, dst = sh.alloc_src(), sh.alloc_dst()
+    pj.fill_random_(src, 7)
+    e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    sh.step(src, dst, events=e)
+    torch.cuda.synchronize()
+    assert e[0].elapsed_time(e[1]) > 0
+    ref = pj.reproject(pj.Enmap(src[0], wcs_in), shape_out, wcs_out).data
+    assert torch.equal(dst[0], ref)
+
+
+def test_fill_random_is_sharding_invariant(pj, dev):
+    """The benchmark's synthetic map is keyed by absolute pixel index, so a strip generated on its own
+    equals the same rows of the full map."""
+    full = torch.empty((40, 64), dtype=torch.float64, device=dev)
+    pj.fill_random_(full, 1234, 0)
+    part = torch.empty((10, 64), dtype=torch.float64, device=dev)
+    pj.fill_random_(part, 1234, 15 * 64)
+    assert torch.equal(part, full[15:25])
+    assert abs(float(full.mean())) < 0.1 and abs(float(full.std()) - 1.0) < 0.1
+    sky = torch.empty((10000, 2), dtype=torch.float64, device=dev)
+    pj.fill_sphere_points_(sky, 42)
+    assert float(sky[:, 0].min()) >= -math.pi and float(sky[:, 0].max()) < math.pi
+    assert float(sky[:, 1].abs().max()) <= math.pi / 2 and abs(float(torch.sin(sky[:, 1]).mean())) < 0.05
