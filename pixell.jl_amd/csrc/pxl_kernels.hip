@@ -693,23 +693,70 @@ __global__ __launch_bounds__(64) void k_reproject_staged(ReprojParams p) {
 
 #include "pxl_reproject_dma.h"
 
-// ---- scattered sample: one lane per point, fused sky2pix!(safe=true) + 2x2 gather.
+// ---- scattered sample: fused sky2pix!(safe=true) [car_proj.jl:165-193] + 2x2 gather + lerp.
+// An irregular gather: each point touches two 16-byte spans in two different rows of a multi-GB map, so
+// the kernel is bound by random-sector fetches, not by bytes.  Each lane handles PXL_SUNR points per trip
+// and issues all their taps before any arithmetic (4x the gathers in flight per lane); tap indices are
+// 32-bit and the RA wrap is one conditional add/subtract (safe sky2pix keeps x within half a period of the
+// map centre), with the oracle's full modulo kept only as the out-of-range path.
+#define PXL_SUNR 4
+__device__ inline int64_t wrap_col(int64_t i, int64_t nx) {          // 1-based column of a periodic map
+    if (i >= 1 - nx && i <= 2 * nx) { if (i > nx) i -= nx; else if (i < 1) i += nx; return i; }
+    i = (i - 1) % nx; if (i < 0) i += nx; return i + 1;
+}
 __global__ __launch_bounds__(256) void k_sample_bilinear(Sky2Pix s, const double* __restrict__ src, int64_t nx,
                                                          int64_t ny, int32_t nc, int64_t row0, int64_t nrows,
                                                          int periodic, int64_t n, const double2* __restrict__ sky,
                                                          double* __restrict__ out) {
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-        double2 ad = sky[k];
-        double x = s2p_x(s, ad.x), y = s2p_y(s, ad.y);
-        bool fin = isfinite(x) && isfinite(y);
-        int32_t i0, j0; double fx, fy;
-        split_cell(x, &i0, &fx);
-        split_cell(y, &j0, &fy);
+    const int64_t chunk = (int64_t)blockDim.x * PXL_SUNR;
+    const int64_t plane = nx * nrows;
+    for (int64_t k0 = (int64_t)blockIdx.x * chunk + threadIdx.x; k0 < n; k0 += (int64_t)gridDim.x * chunk) {
+        double2 ad[PXL_SUNR];
+#pragma unroll
+        for (int u = 0; u < PXL_SUNR; ++u) {
+            int64_t k = k0 + u * blockDim.x;
+            ad[u] = (k < n) ? sky[k] : make_double2(0.0, 0.0);
+        }
+        int64_t o00[PXL_SUNR], o10[PXL_SUNR], o01[PXL_SUNR], o11[PXL_SUNR];   // element offsets, -1 = reads as 0
+        double fx[PXL_SUNR], fy[PXL_SUNR];
+        bool fin[PXL_SUNR];
+#pragma unroll
+        for (int u = 0; u < PXL_SUNR; ++u) {
+            double x = s2p_x(s, ad[u].x), y = s2p_y(s, ad[u].y);
+            fin[u] = isfinite(x) && isfinite(y);
+            int32_t i0, j0;
+            split_cell(x, &i0, &fx[u]);
+            split_cell(y, &j0, &fy[u]);
+            int64_t ia = i0, ib = (int64_t)i0 + 1;
+            bool oka = true, okb = true;
+            if (periodic) { ia = wrap_col(ia, nx); ib = wrap_col(ib, nx); }
+            else { oka = (ia >= 1 && ia <= nx); okb = (ib >= 1 && ib <= nx); }
+            int64_t ja = (int64_t)j0 - 1 - row0, jb = ja + 1;                    // resident row indices
+            bool rowa = (j0 >= 1 && j0 <= ny && ja >= 0 && ja < nrows);
+            bool rowb = ((int64_t)j0 + 1 >= 1 && (int64_t)j0 + 1 <= ny && jb >= 0 && jb < nrows);
+            o00[u] = (rowa && oka) ? ja * nx + (ia - 1) : -1;
+            o10[u] = (rowa && okb) ? ja * nx + (ib - 1) : -1;
+            o01[u] = (rowb && oka) ? jb * nx + (ia - 1) : -1;
+            o11[u] = (rowb && okb) ? jb * nx + (ib - 1) : -1;
+        }
         for (int c = 0; c < nc; ++c) {
-            SrcView m{src + (int64_t)c * nx * nrows, nx, ny, row0, nrows, periodic};
-            double v = bilerp_cells(m, i0, fx, j0, fy);
-            out[(int64_t)c * n + k] = fin ? v : __builtin_nan("");
+            const double* pl = src + (int64_t)c * plane;
+            double m00[PXL_SUNR], m10[PXL_SUNR], m01[PXL_SUNR], m11[PXL_SUNR];
+#pragma unroll
+            for (int u = 0; u < PXL_SUNR; ++u) {
+                m00[u] = o00[u] >= 0 ? pl[o00[u]] : 0.0;
+                m10[u] = o10[u] >= 0 ? pl[o10[u]] : 0.0;
+                m01[u] = o01[u] >= 0 ? pl[o01[u]] : 0.0;
+                m11[u] = o11[u] >= 0 ? pl[o11[u]] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < PXL_SUNR; ++u) {
+                int64_t k = k0 + u * blockDim.x;
+                double top = (1 - fx[u]) * m00[u] + fx[u] * m10[u];
+                double bot = (1 - fx[u]) * m01[u] + fx[u] * m11[u];
+                double v = (1 - fy[u]) * top + fy[u] * bot;
+                if (k < n) out[(int64_t)c * n + k] = fin[u] ? v : __builtin_nan("");
+            }
         }
     }
 }
@@ -1126,9 +1173,14 @@ int pxl_reproject_execute_rows(pxl_reproject_plan* pl, const double* src, double
     const bool use_dma = vec && pl->variant != 2;
     const int pairs = use_dma ? pl->pairs_dma : pl->pairs;
     const int TW = 128 * pairs;
-    p.rh = pl->rh; p.seg = use_dma ? pl->seg_dma : pl->seg; p.dxpos = pl->dxpos; p.dypos = pl->dypos; p.flags = pl->flags;
+    p.seg = use_dma ? pl->seg_dma : pl->seg; p.dxpos = pl->dxpos; p.dypos = pl->dypos; p.flags = pl->flags;
     p.ntx = (int32_t)((pl->nxo + TW - 1) / TW);
-    p.nty = (int32_t)((nr + pl->rh - 1) / pl->rh);
+    // tile height: the configured rh, halved while the launch would leave the chip short of waves
+    // (256 CUs x ~16 resident waves, a few rounds each); small maps and thin strips get shorter tiles
+    int rh = pl->rh;
+    while (rh > 4 && (int64_t)p.ntx * ((nr + rh - 1) / rh) * pl->nc < 4 * 4096) rh >>= 1;
+    p.rh = rh;
+    p.nty = (int32_t)((nr + rh - 1) / rh);
     p.ntiles = (int64_t)p.ntx * p.nty * pl->nc;
     p.tiles_per_xcd = (p.ntiles + 7) / 8;
     int64_t nblocks = p.tiles_per_xcd * 8;
@@ -1222,7 +1274,7 @@ int pxl_sample_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shape_i
     if (n == 0) return PXL_OK;
     Sky2Pix s = sky2pix_setup(*wcs_in, shape_in[0], shape_in[1], 1, PXL_FORM_RECIP);
     int periodic = fabs((double)shape_in[0] * fabs(wcs_in->cdelt[0] * wcs_in->unit) - PXL_TWOPI_D) < 1e-8;
-    hipLaunchKernelGGL(k_sample_bilinear, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, s, src,
+    hipLaunchKernelGGL(k_sample_bilinear, dim3(stream_grid((n + PXL_SUNR - 1) / PXL_SUNR, 256)), dim3(256), 0, (hipStream_t)stream, s, src,
                        shape_in[0], shape_in[1], (int32_t)shape_in[2], src_row0, src_nrows, periodic, n,
                        (const double2*)sky, out);
     return check_launch("k_sample_bilinear");
