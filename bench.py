@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("PXL_BENCH_WORKLOAD", "cfg4"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="verify a sample of the output against the oracle")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the product path); gloo = host-staged halo, only for rehearsing "
+                         "the N-rank flow on a box with fewer GPUs than ranks (with PXL_BENCH_SHARE_GPU=1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,11 +137,16 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     pj.load_library()
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; PXL_BENCH_SHARE_GPU=1 lets several ranks share a device for rehearsals on a 1-GPU box
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank % ndev if os.environ.get("PXL_BENCH_SHARE_GPU") else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     if args.workload == "cfg5":
         result = bench_scattered(args, rank, world, dev)
@@ -163,7 +171,7 @@ def timed_region(world, dev, steps, body):
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
@@ -216,8 +224,9 @@ def bench_reproject(args, rank, world, dev):
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": desc, "shape_in": list(shape_in), "shape_out": list(shape_out) + [nc],
-                   "parallelism": "dec-strip x%d, %d-row halo via RCCL send/recv" % (
-                       world, max([hi - lo for _, lo, hi in sh.recvs], default=0)),
+                   "parallelism": "dec-strip x%d, %d-row halo via %s send/recv" % (
+                       world, max([hi - lo for _, lo, hi in sh.recvs], default=0),
+                       "RCCL" if (world == 1 or dist.get_backend() == "nccl") else "gloo (host-staged REHEARSAL)"),
                    "halo_bytes_per_rank": sh.halo_bytes(),
                    "bytes_per_output_value": round(8.0 * (nx * ny + nxo * nyo) / (nxo * nyo), 3)},
         "roofline": {"bound": "hbm", "kernel": "k_reproject_dma",

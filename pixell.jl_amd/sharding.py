@@ -142,10 +142,15 @@ class DecStripLayout:
         return best          # relative to the dst window
 
     # -- halo exchange (backend-agnostic: RCCL for cuda tensors, gloo for cpu tensors)
-    def make_staging(self, like: torch.Tensor):
+    def make_staging(self, like: torch.Tensor, group=None):
+        """Packed (nc, rows, nx) message buffers.  They live where the transport can reach them: on the
+        GPU for RCCL, in host memory when a gloo group moves GPU data (1-GPU rehearsals of the N-rank flow)."""
         nx, _, nc = self.shape_in
-        send = [torch.empty((nc, hi - lo, nx), dtype=like.dtype, device=like.device) for _, lo, hi in self.sends]
-        recv = [torch.empty((nc, hi - lo, nx), dtype=like.dtype, device=like.device) for _, lo, hi in self.recvs]
+        dev = like.device
+        if like.is_cuda and dist.is_initialized() and dist.get_backend(group) == "gloo":
+            dev = torch.device("cpu")
+        send = [torch.empty((nc, hi - lo, nx), dtype=like.dtype, device=dev) for _, lo, hi in self.sends]
+        recv = [torch.empty((nc, hi - lo, nx), dtype=like.dtype, device=dev) for _, lo, hi in self.recvs]
         return send, recv
 
     def start_halo_exchange(self, src: torch.Tensor, staging, group=None):
@@ -200,7 +205,7 @@ class DecStripReprojector(DecStripLayout):
                 events[1].record()
             return dst
         if self._staging is None:
-            self._staging = self.make_staging(src)
+            self._staging = self.make_staging(src, self.group)
         works = self.start_halo_exchange(src, self._staging, self.group)
         self.plan.build_tables()
         i_lo, i_hi = self.interior
