@@ -145,11 +145,26 @@ int pxl_reproject_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shap
                                    const pxl_car_wcs* wcs_out, const int64_t shape_out[2], double* dst,
                                    void* stream);
 
+/* ---- Generic (non-separable) bilinear reprojection between CAR and Gnomonic maps: per output pixel
+ *      pix2sky(out) -> sky2pix(in) -> 2x2 gather, with the evaluators of car_proj.jl / tan_proj.jl.
+ *      FP64-transcendental bound; full maps only.  proj codes: PXL_PROJ_CAR, PXL_PROJ_TAN.                   */
+#define PXL_PROJ_CAR 0
+#define PXL_PROJ_TAN 1
+int pxl_reproject_generic_bilinear_f64(const pxl_car_wcs* wcs_in, int proj_in, const int64_t shape_in[3],
+                                       const double* src, const pxl_car_wcs* wcs_out, int proj_out,
+                                       const int64_t shape_out[2], double* dst, void* stream);
+
 /* ---- Scattered bilinear sample: (x, y) = sky2pix!(shape_in, wcs_in, sky2xN; safe=true)
  *      [car_proj.jl:165-193] then the same 2x2 gather + lerp.  out is (n, nc) column-major.          */
 int pxl_sample_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], const double* src,
                                 int64_t src_row0, int64_t src_nrows,
                                 int64_t n, const double* sky2xN, double* out, void* stream);
+
+/* ---- FITS image staging (the on-disk format either side of the path: read_map / write_map, enmap.jl:198-237).
+ *      raw_be: device copy of the HDU's big-endian data block, n elements of BITPIX -64 (or -32 for decode);
+ *      decode writes native Float64 (in place allowed for -64), encode writes big-endian Float64.          */
+int pxl_fits_decode_f64(const void* raw_be, double* dst, int64_t n, int bitpix, void* stream);
+int pxl_fits_encode_f64(const double* src, void* raw_be, int64_t n, void* stream);
 
 /* ---- synthetic inputs (benchmark plumbing, deterministic counter-based generator):
  *      fill n doubles with N(0,1) (kind 0) or U[0,1) (kind 1) from splitmix64(seed, index+offset);

@@ -244,3 +244,17 @@ def reproject_src_rows(wcs_in, shape_in, wcs_out, shape_out, dst_row0, dst_nrows
                                           C.byref(lo), C.byref(hi))
     assert rc == 0
     return lo.value, hi.value
+
+
+def reproject_generic(wcs_in, proj_in, shape_in, src, wcs_out, proj_out, shape_out):
+    """CAR (proj 0) / Gnomonic (proj 1) non-separable reprojection.  src: (nc, ny, nx); returns (nc, nyo, nxo)."""
+    nx, ny, nc = _shape3(shape_in)
+    nxo, nyo = int(shape_out[0]), int(shape_out[1])
+    src = _f64(src)
+    assert src.size == nx * ny * nc
+    dst = np.empty((nc, nyo, nxo))
+    rc = lib().pxl_reproject_generic_bilinear_f64_cpu(
+        C.byref(_w(wcs_in)), C.c_int(proj_in), _i64((nx, ny, nc)), _dp(src), C.byref(_w(wcs_out)), C.c_int(proj_out),
+        _i64((nxo, nyo)), _dp(dst))
+    assert rc == 0
+    return dst

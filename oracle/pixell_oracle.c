@@ -457,3 +457,40 @@ int pxl_reproject_src_rows_cpu(const pxl_car_wcs* win, const int64_t* shape_in,
     free(xs);
     return 0;
 }
+
+/* ---- Generic (non-separable) bilinear reprojection between CAR (proj 0) and Gnomonic (proj 1) maps (N2):
+ *      per output pixel pix2sky(out) [car_proj.jl:146-147 safe=false | tan_proj.jl:59-75], then
+ *      sky2pix(in) [car_proj.jl:225-231 safe=true | tan_proj.jl:44-57], then the R1 2x2 gather.
+ *      A sky point behind a Gnomonic source's tangent plane (cos c <= 0) reads as 0.  PARITY UNPINNED
+ *      (no reprojection in the reference); libm-level tolerance against the device.                     */
+int pxl_reproject_generic_bilinear_f64_cpu(const pxl_car_wcs* win, int proj_in, const int64_t* shape_in,
+                                           const double* src, const pxl_car_wcs* wout, int proj_out,
+                                           const int64_t* shape_out, double* dst) {
+    int64_t nx = shape_in[0], ny = shape_in[1], nc = shape_in[2];
+    int64_t nxo = shape_out[0], nyo = shape_out[1];
+    int periodic = (proj_in == 0) && pxl_car_is_periodic_cpu(win, nx);
+    s2p_t s = s2p_setup(win, shape_in, 1, PXL_FORM_DIV);
+    double oa0 = wout->crval[0] * wout->unit, od0 = wout->crval[1] * wout->unit;
+    double oda = wout->cdelt[0] * wout->unit, odd = wout->cdelt[1] * wout->unit;
+    double ia0 = win->crval[0] * (PXL_PI / 180), id0 = win->crval[1] * (PXL_PI / 180);
+    #pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t jr = 0; jr < nyo; ++jr) {
+        for (int64_t i = 0; i < nxo; ++i) {
+            double ip = (double)(i + 1), jp = (double)(jr + 1), ra, dec, x, y;
+            if (proj_out == 1) pxl_pix2sky_tan_f64_cpu(wout, 1, &ip, &jp, &ra, &dec);
+            else { ra = oa0 + (ip - wout->crpix[0]) * oda; dec = od0 + (jp - wout->crpix[1]) * odd; }
+            int visible = 1;
+            if (proj_in == 1) {
+                pxl_sky2pix_tan_f64_cpu(win, 1, &ra, &dec, &x, &y);
+                visible = (sin(id0) * sin(dec) + cos(dec) * cos(ra - ia0) * cos(id0)) > 0.0;
+            } else s2p_eval(&s, ra, dec, &x, &y);
+            for (int64_t c = 0; c < nc; ++c) {
+                srcmap_t m = { src + c * nx * ny, nx, ny, 0, ny, periodic };
+                double v = bilerp(&m, x, y);                 /* NaN when x or y is not finite */
+                if (!visible && !isnan(v)) v = 0.0;
+                dst[c * nxo * nyo + jr * nxo + i] = v;
+            }
+        }
+    }
+    return 0;
+}

@@ -54,7 +54,10 @@ SIGNATURES = {
     "pxl_reproject_plan_set_variant": (C.c_int, [_P, C.c_int]),
     "pxl_reproject_plan_destroy": (C.c_int, [_P]),
     "pxl_reproject_car_bilinear_f64": (C.c_int, [_WP, _SHP, _P, _WP, _SHP, _P, _P]),
+    "pxl_reproject_generic_bilinear_f64": (C.c_int, [_WP, C.c_int, _SHP, _P, _WP, C.c_int, _SHP, _P, _P]),
     "pxl_sample_car_bilinear_f64": (C.c_int, [_WP, _SHP, _P, _I64, _I64, _I64, _P, _P, _P]),
+    "pxl_fits_decode_f64": (C.c_int, [_P, _P, _I64, C.c_int, _P]),
+    "pxl_fits_encode_f64": (C.c_int, [_P, _P, _I64, _P]),
     "pxl_fill_random_f64": (C.c_int, [_P, _I64, C.c_uint64, C.c_uint64, C.c_int, _P]),
     "pxl_fill_sphere_points_f64": (C.c_int, [_P, _I64, C.c_uint64, C.c_uint64, _P]),
 }

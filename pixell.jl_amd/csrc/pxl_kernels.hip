@@ -693,6 +693,44 @@ __global__ __launch_bounds__(64) void k_reproject_staged(ReprojParams p) {
 
 #include "pxl_reproject_dma.h"
 
+// ---- generic (non-separable) bilinear reprojection between CAR and Gnomonic maps (N2).
+// Per output pixel: (ra, dec) = pix2sky(out) [car_proj.jl:146-147 safe=false | tan_proj.jl:59-75];
+// (x, y) = sky2pix(in) [car_proj.jl:225-231 safe=true | tan_proj.jl:44-57]; 2x2 direct taps + lerp.
+// A sky point behind a Gnomonic source's tangent plane (cos c <= 0) is not on that map: it reads as 0.
+// FP64-transcendental bound (about ten libm calls per pixel), tolerance-checked rather than bit-exact.
+struct GenericParams {
+    const double* src; double* dst;
+    int64_t nx, ny, nxo, nyo;
+    int32_t nc, periodic, proj_in, proj_out;
+    CarAffine out_car; TanParams out_tan;
+    Sky2Pix in_car; TanParams in_tan;
+};
+__global__ __launch_bounds__(256) void k_reproject_generic(GenericParams p) {
+    const int64_t total = p.nxo * p.nyo;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int64_t jr = t / p.nxo, i = t - jr * p.nxo;
+        double ra, dec;
+        if (p.proj_out == PXL_PROJ_TAN) tan_pix2sky(p.out_tan, (double)(i + 1), (double)(jr + 1), &ra, &dec);
+        else { ra = p2s_ra(p.out_car, (double)(i + 1)); dec = p2s_dec(p.out_car, (double)(jr + 1)); }
+        double x, y;
+        bool visible = true;
+        if (p.proj_in == PXL_PROJ_TAN) {
+            tan_sky2pix(p.in_tan, ra, dec, &x, &y);
+            visible = (p.in_tan.sd0 * sin(dec) + cos(dec) * cos(ra - p.in_tan.a0) * p.in_tan.cd0) > 0.0;
+        } else { x = s2p_x(p.in_car, ra); y = s2p_y(p.in_car, dec); }
+        const bool fin = isfinite(x) && isfinite(y);
+        int32_t i0, j0; double fx, fy;
+        split_cell(x, &i0, &fx);
+        split_cell(y, &j0, &fy);
+        for (int c = 0; c < p.nc; ++c) {
+            SrcView m{p.src + (int64_t)c * p.nx * p.ny, p.nx, p.ny, 0, p.ny, p.periodic};
+            double v = visible ? bilerp_cells(m, i0, fx, j0, fy) : 0.0;
+            p.dst[(int64_t)c * total + t] = fin ? v : __builtin_nan("");
+        }
+    }
+}
+
 // ---- scattered sample: fused sky2pix!(safe=true) [car_proj.jl:165-193] + 2x2 gather + lerp.
 // An irregular gather: each point touches two 16-byte spans in two different rows of a multi-GB map, so
 // the kernel is bound by random-sector fetches, not by bytes.  Each lane handles PXL_SUNR points per trip
@@ -757,6 +795,37 @@ __global__ __launch_bounds__(256) void k_sample_bilinear(Sky2Pix s, const double
                 double v = (1 - fy[u]) * top + fy[u] * bot;
                 if (k < n) out[(int64_t)c * n + k] = fin[u] ? v : __builtin_nan("");
             }
+        }
+    }
+}
+
+// ---- FITS staging (N3): big-endian image data <-> native Float64, on the device (enmap.jl:198-237 reads and
+// writes BITPIX -64/-32 image HDUs through CFITSIO; here the raw bytes are copied to HBM and swapped there).
+__global__ __launch_bounds__(256) void k_bswap_to_f64(const void* raw, double* dst,
+                                                      int64_t n, int bitpix) {
+    const int64_t chunk = (int64_t)blockDim.x * 4;
+    for (int64_t k0 = (int64_t)blockIdx.x * chunk + threadIdx.x; k0 < n; k0 += (int64_t)gridDim.x * chunk) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int64_t k = k0 + u * blockDim.x;
+            if (k >= n) continue;
+            if (bitpix == -64) {
+                uint64_t v = __builtin_bswap64(reinterpret_cast<const uint64_t*>(raw)[k]);
+                dst[k] = __longlong_as_double((long long)v);
+            } else {            // -32: IEEE single, widened exactly
+                uint32_t v = __builtin_bswap32(reinterpret_cast<const uint32_t*>(raw)[k]);
+                dst[k] = (double)__uint_as_float(v);
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_f64_to_be(const double* __restrict__ src, uint64_t* __restrict__ raw, int64_t n) {
+    const int64_t chunk = (int64_t)blockDim.x * 4;
+    for (int64_t k0 = (int64_t)blockIdx.x * chunk + threadIdx.x; k0 < n; k0 += (int64_t)gridDim.x * chunk) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int64_t k = k0 + u * blockDim.x;
+            if (k < n) raw[k] = __builtin_bswap64((uint64_t)__double_as_longlong(src[k]));
         }
     }
 }
@@ -1262,6 +1331,31 @@ int pxl_reproject_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shap
     return rc;
 }
 
+int pxl_reproject_generic_bilinear_f64(const pxl_car_wcs* wcs_in, int proj_in, const int64_t shape_in[3],
+                                       const double* src, const pxl_car_wcs* wcs_out, int proj_out,
+                                       const int64_t shape_out[2], double* dst, void* stream) {
+    if (!wcs_ok(wcs_in) || !wcs_ok(wcs_out)) return fail(PXL_EINVAL, "reproject_generic: invalid WCS");
+    if (!shape_in || !shape_out) return fail(PXL_EINVAL, "reproject_generic: null shape");
+    if (shape_in[0] < 1 || shape_in[1] < 1 || shape_in[2] < 1 || shape_out[0] < 1 || shape_out[1] < 1)
+        return fail(PXL_EINVAL, "reproject_generic: shapes must be positive");
+    if ((proj_in != PXL_PROJ_CAR && proj_in != PXL_PROJ_TAN) || (proj_out != PXL_PROJ_CAR && proj_out != PXL_PROJ_TAN))
+        return fail(PXL_EINVAL, "reproject_generic: unknown projection code");
+    if (!src || !dst) return fail(PXL_EINVAL, "reproject_generic: null src/dst");
+    GenericParams p;
+    memset(&p, 0, sizeof(p));
+    p.src = src; p.dst = dst;
+    p.nx = shape_in[0]; p.ny = shape_in[1]; p.nc = (int32_t)shape_in[2];
+    p.nxo = shape_out[0]; p.nyo = shape_out[1];
+    p.proj_in = proj_in; p.proj_out = proj_out;
+    p.periodic = (proj_in == PXL_PROJ_CAR) &&
+                 fabs((double)p.nx * fabs(wcs_in->cdelt[0] * wcs_in->unit) - PXL_TWOPI_D) < 1e-8;
+    if (proj_out == PXL_PROJ_TAN) p.out_tan = tan_setup(*wcs_out); else p.out_car = car_affine(*wcs_out);
+    if (proj_in == PXL_PROJ_TAN) p.in_tan = tan_setup(*wcs_in);
+    else p.in_car = sky2pix_setup(*wcs_in, p.nx, p.ny, 1, PXL_FORM_DIV);
+    hipLaunchKernelGGL(k_reproject_generic, dim3(stream_grid(p.nxo * p.nyo, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("k_reproject_generic");
+}
+
 int pxl_sample_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], const double* src,
                                 int64_t src_row0, int64_t src_nrows, int64_t n, const double* sky, double* out,
                                 void* stream) {
@@ -1278,6 +1372,21 @@ int pxl_sample_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shape_i
                        shape_in[0], shape_in[1], (int32_t)shape_in[2], src_row0, src_nrows, periodic, n,
                        (const double2*)sky, out);
     return check_launch("k_sample_bilinear");
+}
+
+int pxl_fits_decode_f64(const void* raw_be, double* dst, int64_t n, int bitpix, void* stream) {
+    if (n < 0 || (n > 0 && (!raw_be || !dst))) return fail(PXL_EINVAL, "fits_decode: null buffer or negative n");
+    if (bitpix != -64 && bitpix != -32) return fail(PXL_EINVAL, "fits_decode: BITPIX %d not supported (only -64, -32)", bitpix);
+    if (n == 0) return PXL_OK;
+    hipLaunchKernelGGL(k_bswap_to_f64, dim3(stream_grid((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, raw_be, dst, n, bitpix);
+    return check_launch("k_bswap_to_f64");
+}
+
+int pxl_fits_encode_f64(const double* src, void* raw_be, int64_t n, void* stream) {
+    if (n < 0 || (n > 0 && (!raw_be || !src))) return fail(PXL_EINVAL, "fits_encode: null buffer or negative n");
+    if (n == 0) return PXL_OK;
+    hipLaunchKernelGGL(k_f64_to_be, dim3(stream_grid((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, src, (uint64_t*)raw_be, n);
+    return check_launch("k_f64_to_be");
 }
 
 int pxl_fill_random_f64(double* dst, int64_t n, uint64_t seed, uint64_t offset, int kind, void* stream) {

@@ -329,13 +329,33 @@ class ReprojectPlan:
 def reproject(m: Enmap, shape_out, wcs_out, out: Enmap = None, plan: ReprojectPlan = None) -> Enmap:
     """Bilinear CAR -> CAR reprojection of every component of `m` onto (shape_out, wcs_out).
     Not in the reference; composes posmap(out) o sky2pix(in) o 2x2 gather + lerp."""
+    nxo, nyo = int(shape_out[0]), int(shape_out[1])
+    if isinstance(m.wcs, Gnomonic) or isinstance(wcs_out, Gnomonic):
+        return _reproject_generic(m, (nxo, nyo), wcs_out, out)
     if plan is None:
         plan = ReprojectPlan(m.shape, m.wcs, shape_out, wcs_out, device=m.device)
-    nxo, nyo = int(shape_out[0]), int(shape_out[1])
     if out is None:
         oshape = (nyo, nxo) if m.data.dim() == 2 else (m.data.shape[0], nyo, nxo)
         out = Enmap(torch.empty(oshape, dtype=torch.float64, device=m.device), wcs_out)
     plan.execute(m.data, out.data)
+    return out
+
+
+def _reproject_generic(m: Enmap, shape_out, wcs_out, out=None) -> Enmap:
+    """CAR <-> Gnomonic (non-separable) bilinear reprojection: pxl_reproject_generic_bilinear_f64."""
+    data = _dev_f64(m.data, "map data")
+    for w in (m.wcs, wcs_out):
+        if not isinstance(w, (AbstractCARWCS, Gnomonic)):
+            raise TypeError("generic reprojection handles CAR and Gnomonic WCS only")
+    nc = data.shape[0] if data.dim() == 3 else 1
+    if out is None:
+        oshape = (shape_out[1], shape_out[0]) if data.dim() == 2 else (nc, shape_out[1], shape_out[0])
+        out = Enmap(torch.empty(oshape, dtype=torch.float64, device=data.device), wcs_out)
+    code = lambda w: 1 if isinstance(w, Gnomonic) else 0   # PXL_PROJ_TAN / PXL_PROJ_CAR
+    with torch.cuda.device(data.device):
+        _lib.check(_lib.load().pxl_reproject_generic_bilinear_f64(
+            _wcs_ref(m.wcs), code(m.wcs), _lib.shape_arr((m.shape[0], m.shape[1], nc)), _ptr(data),
+            _wcs_ref(wcs_out), code(wcs_out), _shape2(shape_out), _ptr(out.data), _stream(data)))
     return out
 
 

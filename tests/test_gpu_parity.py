@@ -504,3 +504,39 @@ def test_unwind_ties_and_nonfinite(pj, O, dev):
     assert np.array_equal(np.isnan(got), np.isnan(exp))
     assert bits_equal(got[:7000], exp[:7000]) and bits_equal(got[:12345, 1], exp[:12345, 1])
     assert np.isnan(got[7000:, 0]).all() and np.isnan(got[12345:, 1]).all()
+
+
+# ---- CAR <-> Gnomonic (non-separable) reprojection: tolerance-checked (FP64 transcendentals) ---------
+
+def test_generic_reproject_car_tan(pj, O, dev, literals):
+    g = literals["gnomonic"]
+    tan_wcs = pj.Gnomonic(g["cdelt"], g["crpix"], g["crval"])
+    tan_shape = (600, 500)
+    tan_wcs = pj.Gnomonic(g["cdelt"], (300.5, 250.5), g["crval"])
+    # a CAR box around the same field (RA 97.5 deg, DEC -7.5 deg), 0.5 arcmin pixels like the TAN patch
+    car_shape, car_wcs = pj.geometry([[101 * DEG, 94 * DEG], [-11 * DEG, -4 * DEG]], 0.5 * ARCMIN)
+    rng = np.random.default_rng(12)
+    # smooth maps (so a last-bit difference in x, y moves values by ~1e-13, not by a pixel-to-pixel jump)
+    def smooth(shape, nc):
+        yy, xx = np.meshgrid(np.arange(shape[1]), np.arange(shape[0]), indexing="ij")
+        return np.stack([np.sin(0.01 * (c + 1) * xx) * np.cos(0.013 * yy) + 0.001 * c * xx for c in range(nc)])
+    for (s_in, w_in, p_in), (s_out, w_out, p_out), nc in (
+            ((car_shape, car_wcs, 0), (tan_shape, tan_wcs, 1), 2),
+            ((tan_shape, tan_wcs, 1), (car_shape, car_wcs, 0), 1),
+            ((tan_shape, tan_wcs, 1), ((300, 260), pj.Gnomonic(g["cdelt"], (120.0, 100.0), (98.0, -7.0)), 1), 1)):
+        src = smooth(s_in, nc)
+        m = pj.Enmap(to_dev(src if nc > 1 else src[0], dev), w_in)
+        out = pj.reproject(m, s_out, w_out)
+        assert out.shape[:2] == tuple(s_out)
+        got = out.data.cpu().numpy().reshape(nc, s_out[1], s_out[0])
+        exp = O.reproject_generic(w_in, p_in, (s_in[0], s_in[1], nc), src, w_out, p_out, s_out)
+        assert np.isfinite(got).all()
+        assert np.abs(got - exp).max() < 1e-9, (p_in, p_out, np.abs(got - exp).max())
+        assert np.abs(exp).max() > 0.1                      # the maps overlap: this is not a comparison of zeros
+    # consistency with the separable kernel when both maps are CAR
+    fs = pj.fullsky_geometry(2 * math.pi / 200)
+    fs2 = pj.fullsky_geometry(2 * math.pi / 300)
+    src = smooth(fs[0], 1)
+    exp = O.reproject(fs[1], fs[0], src, fs2[1], fs2[0])
+    gen = O.reproject_generic(fs[1], 0, (fs[0][0], fs[0][1], 1), src, fs2[1], 0, fs2[0])
+    assert bits_equal(gen, exp)
