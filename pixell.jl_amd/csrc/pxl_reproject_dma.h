@@ -21,8 +21,6 @@
 // zero fill, and the DMA count stays exact).
 #pragma once
 
-typedef double v2d_t __attribute__((ext_vector_type(2)));
-
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -75,18 +73,12 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
     const int64_t b = blockIdx.x;
     const int64_t t = (p.flags & 4) ? b : (b & 7) * p.tiles_per_xcd + (b >> 3);
     if (t >= p.ntiles) return;
-    int tx, ty, c;
-    if (p.flags & 16) {           // experiment: DEC-fastest tile order
-        ty = (int)(t % p.nty);
-        const int64_t trest = t / p.nty;
-        tx = (int)(trest % p.ntx);
-        c = (int)(trest / p.ntx);
-    } else {
-        tx = (int)(t % p.ntx);
-        const int64_t trest = t / p.ntx;
-        ty = (int)(trest % p.nty);
-        c = (int)(trest / p.nty);
-    }
+    // RA-fastest tile order (DEC-fastest, non-temporal loads and non-temporal stores were all measured:
+    // each within 1 % of this; profiles/r01_tuning_sweeps.log)
+    const int tx = (int)(t % p.ntx);
+    const int64_t trest = t / p.ntx;
+    const int ty = (int)(trest % p.nty);
+    const int c = (int)(trest / p.nty);
 
     const double* splane = p.src + (int64_t)c * p.nx * p.src_nrows;
     double* dplane = p.dst + (int64_t)c * p.nxo * p.dst_nrows;
@@ -231,12 +223,7 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
             }
             double* o = orow + q * 128;
             if (p.flags & 2) { if (v[0] == 1.2345e300) o[0] = v[1]; }       // diagnostics: keep v live, never store
-            else if (vec_store) {
-                if (act[q][0]) {
-                    if (p.flags & 8) { v2d_t w = {v[0], v[1]}; __builtin_nontemporal_store(w, reinterpret_cast<v2d_t*>(o)); }
-                    else *reinterpret_cast<double2*>(o) = make_double2(v[0], v[1]);
-                }
-            }
+            else if (vec_store) { if (act[q][0]) *reinterpret_cast<double2*>(o) = make_double2(v[0], v[1]); }
             else { if (act[q][0]) o[0] = v[0]; if (act[q][1]) o[1] = v[1]; }
         }
         orow += p.nxo;
