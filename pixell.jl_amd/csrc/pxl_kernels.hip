@@ -1098,8 +1098,9 @@ int pxl_reproject_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[
     if (!shape_in || !shape_out) return fail(PXL_EINVAL, "plan_create: null shape");
     if (shape_in[0] < 1 || shape_in[1] < 1 || shape_in[2] < 1 || shape_out[0] < 1 || shape_out[1] < 1)
         return fail(PXL_EINVAL, "plan_create: shapes must be positive");
-    if (shape_in[0] > 1000000000 || shape_in[1] > 1000000000 || shape_out[0] > 1000000000 || shape_out[1] > 1000000000)
-        return fail(PXL_EINVAL, "plan_create: axis longer than 1e9 pixels");
+    // int32 cell tables and 32-bit byte offsets within a source row: nx * 8 must stay below 2^32
+    if (shape_in[0] > 400000000 || shape_in[1] > 1000000000 || shape_out[0] > 1000000000 || shape_out[1] > 1000000000)
+        return fail(PXL_EINVAL, "plan_create: axis too long (source RA axis <= 4e8, others <= 1e9 pixels)");
     if (src_row0 < 0 || src_nrows < 0 || src_row0 + src_nrows > shape_in[1])
         return fail(PXL_EINVAL, "plan_create: source window outside the map");
     if (dst_row0 < 0 || dst_nrows < 0 || dst_row0 + dst_nrows > shape_out[1])

@@ -93,6 +93,48 @@ class Enmap:
         return Enmap(d.contiguous(), new_wcs)
 
 
+    # ---- broadcasting (enmap.jl:86-174): elementwise arithmetic keeps the first operand's WCS
+    #      (combine(x::AbstractWCSTransform, y) = copy(x), enmap.jl:107-110); the arithmetic itself is the
+    #      parent array's (torch), exactly as the reference defers to the parent's BroadcastStyle
+    def _binary(self, other, op, reflected=False):
+        o = other.data if isinstance(other, Enmap) else other
+        res = op(o, self.data) if reflected else op(self.data, o)
+        return Enmap(res, self.wcs)
+
+    def __add__(self, o): return self._binary(o, torch.add)
+    def __radd__(self, o): return self._binary(o, torch.add, True)
+    def __sub__(self, o): return self._binary(o, torch.sub)
+    def __rsub__(self, o): return self._binary(o, torch.sub, True)
+    def __mul__(self, o): return self._binary(o, torch.mul)
+    def __rmul__(self, o): return self._binary(o, torch.mul, True)
+    def __truediv__(self, o): return self._binary(o, torch.div)
+    def __rtruediv__(self, o): return self._binary(o, torch.div, True)
+    def __pow__(self, o): return self._binary(o, torch.pow)
+    def __neg__(self): return Enmap(-self.data, self.wcs)
+
+    def assign(self, other):
+        """m .= other (broadcasted assignment keeps m's WCS; test_enmap.jl:83-88)."""
+        self.data.copy_(other.data if isinstance(other, Enmap) else other)
+        return self
+
+    def sum(self):
+        return self.data.sum()
+
+    # ---- pad (car_proj.jl:280-327): zero padding with the WCS shifted (center) or kept (corner)
+    def pad(self, npix_ra, npix_dec=None, mode="center"):
+        from .geometry import pad_geometry
+        npix_dec = npix_ra if npix_dec is None else npix_dec
+        new_shape, new_wcs = pad_geometry(self.shape, self.wcs, npix_ra, npix_dec, mode)
+        lead = tuple(self.data.shape[:-2])
+        arr = torch.zeros(lead + (new_shape[1], new_shape[0]), dtype=self.data.dtype, device=self.data.device)
+        ny, nx = self.data.shape[-2:]
+        if mode == "center":
+            arr[..., npix_dec:npix_dec + ny, npix_ra:npix_ra + nx] = self.data
+        else:
+            arr[..., :ny, :nx] = self.data
+        return Enmap(arr, new_wcs)
+
+
 def getwcs(x):
     """enmap.jl:24-25"""
     return x.wcs if isinstance(x, Enmap) else NoWCS()

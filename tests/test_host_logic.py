@@ -193,3 +193,26 @@ def test_host_row_cells_match_oracle_tables(pj, O):
         cells = host_row_cells(shape_in, w_in, shape_out, w_out)
         _, ys = O.reproject_tables(w_in, shape_in, w_out, shape_out)
         assert np.array_equal(cells, np.floor(ys).astype(np.int64))
+
+
+def test_enmap_broadcasting_and_pad(pj):
+    """test_enmap.jl:94-135 (broadcasting equals plain-array broadcasting, WCS kept) and :167-180 (pad)."""
+    import torch
+    shape, w = pj.fullsky_geometry(1 * DEG, dims=(3,))
+    g = torch.Generator().manual_seed(0)
+    A = torch.rand((3, shape[1], shape[0]), dtype=torch.float64, generator=g)
+    B = torch.rand((3, shape[1], shape[0]), dtype=torch.float64, generator=g)
+    ma, mb = pj.Enmap(A, w), pj.Enmap(B, w)
+    assert torch.equal((ma + mb).data, A + B) and torch.equal((ma + B).data, A + B)
+    assert torch.equal((ma ** 2).data, A ** 2) and torch.equal((2.0 * ma - 1.0).data, 2.0 * A - 1.0)
+    assert (ma + mb).wcs == w and (ma ** 2).wcs == w
+    c = ma.similar().assign(mb)
+    assert torch.equal(c.data, B) and c.wcs == w
+    # pad: shape grows, crpix shifts by the padding (center) or stays (corner), data sits in the middle
+    m2 = pj.Enmap(A[0], w)
+    p = m2.pad(3, 5)
+    assert p.shape == (shape[0] + 6, shape[1] + 10) and p.wcs.crpix == (w.crpix[0] + 3, w.crpix[1] + 5)
+    assert torch.equal(p.data[5:-5, 3:-3], A[0]) and float(p.data[:5].abs().sum()) == 0.0
+    assert torch.equal(p.view((4, shape[0] + 3), (6, shape[1] + 5)).data, A[0])         # pad round trip
+    q = m2.pad(2, 2, mode="corner")
+    assert q.shape == (shape[0] + 2, shape[1] + 2) and q.wcs == w and torch.equal(q.data[:shape[1], :shape[0]], A[0])
