@@ -38,6 +38,15 @@ import pixell_jl_amd as pj        # noqa: E402
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def baseline_metric():
+    """BASELINE.json's metric string (the unit is its leading token, Mpix/s)."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except Exception:
+        return "Mpix/s CAR bilinear reproject (Float64) + % HBM roofline, 1/2/4/8 MI355X"
+
+
 def workload_geometry(name):
     if name == "cfg4":
         shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 43200, dims=(3,))
@@ -217,7 +226,7 @@ def bench_reproject(args, rank, world, dev):
     traffic = load_traffic(args.workload) if world == 1 else None
 
     result = {
-        "metric": "Mpix/s CAR bilinear reproject (Float64)",
+        "metric": baseline_metric(),
         "value": round(mpix, 1), "unit": "Mpix/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4),

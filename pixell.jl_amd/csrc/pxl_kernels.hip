@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_sky2pix_soa(Sky2Pix s, int64_t n, const
 //   2. r := inclusive prefix sum of c                                    (two-level block scan, int32)
 //   3. verify every k with the reference's own floating-point formula: t = rint((m[k] - (m[k-1] - r[k-1]*P))/P);
 //      where t != r[k], fix c_k += t - r[k] and raise a flag
-//   4. repeat 2-3 once; if the second verification is clean, r is -- by induction from r_0 = 0 -- exactly
+//   4. if anything was fixed, repeat 2-3 once (device-gated); a clean verification means r is -- by induction from r_0 = 0 -- exactly
 //      the sequential result, and y[k] = m[k] - r[k]*P + ref is written.  Otherwise (adversarial ties) the
 //      exact serial kernel below runs instead.  Nothing synchronises with the host.
 // PARITY UNPINNED (DSP.jl is not in the reference tree); the oracle's pxl_unwind_row_cpu is the definition.
@@ -168,8 +168,9 @@ __global__ __launch_bounds__(256) void k_unwrap_incr(int64_t n, const double* __
 
 // local inclusive scan of 4096-element blocks; blockIdx.y = coordinate row
 __global__ __launch_bounds__(256) void k_scan_local(int64_t n, const int8_t* __restrict__ c, int32_t* __restrict__ rloc,
-                                                    int32_t* __restrict__ bsum, int64_t nb) {
+                                                    int32_t* __restrict__ bsum, int64_t nb, const int32_t* __restrict__ gate) {
     __shared__ int32_t wsum[4];
+    if (gate && *gate == 0) return;         // second pass: only if the first verification found mismatches
     const int row = blockIdx.y;
     const int64_t base = (int64_t)blockIdx.x * PXL_SCAN_BLOCK + (int64_t)threadIdx.x * PXL_SCAN_ITEMS;
     int32_t v[PXL_SCAN_ITEMS];
@@ -202,9 +203,11 @@ __global__ __launch_bounds__(256) void k_scan_local(int64_t n, const int8_t* __r
 }
 
 // exclusive scan of the block totals (one block per coordinate row walks them with a running carry)
-__global__ __launch_bounds__(1024) void k_scan_bsums(int64_t nb, const int32_t* __restrict__ bsum, int32_t* __restrict__ boff) {
+__global__ __launch_bounds__(1024) void k_scan_bsums(int64_t nb, const int32_t* __restrict__ bsum, int32_t* __restrict__ boff,
+                                                     const int32_t* __restrict__ gate) {
     __shared__ int32_t wsum[16];
     __shared__ int32_t carry_s;
+    if (gate && *gate == 0) return;
     const int row = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
@@ -237,7 +240,8 @@ __device__ inline int32_t scan_value(const int32_t* rloc, const int32_t* boff, i
 __global__ __launch_bounds__(256) void k_unwrap_verify(int64_t n, const double* __restrict__ m2, double period,
                                                        int8_t* __restrict__ c, const int32_t* __restrict__ rloc,
                                                        const int32_t* __restrict__ boff, int64_t nb,
-                                                       int32_t* __restrict__ flag) {
+                                                       int32_t* __restrict__ flag, const int32_t* __restrict__ gate) {
+    if (gate && *gate == 0) return;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     bool bad = false;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; k < n; k += stride) {
@@ -261,7 +265,8 @@ __global__ __launch_bounds__(256) void k_unwrap_verify(int64_t n, const double* 
 __global__ __launch_bounds__(256) void k_unwrap_apply(int64_t n, double* __restrict__ m2, double period, double ref,
                                                       const int32_t* __restrict__ rloc, const int32_t* __restrict__ boff,
                                                       int64_t nb, const int32_t* __restrict__ flag) {
-    if (*flag) return;                      // verification failed: the serial kernel produces the answer
+    // flag[0]: pass 1 found mismatches; flag[1]: pass 2 (run only then) still found some
+    if (flag[0] && flag[1]) return;         // unverified: the serial kernel produces the answer
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
         double2 m = *reinterpret_cast<const double2*>(m2 + 2 * k);
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(256) void k_unwrap_apply(int64_t n, double* __restr
 // holds m = rewind(.) - ref.  gate: run only if *gate != 0 (NULL = always).
 __global__ __launch_bounds__(64) void k_unwind_rows(int64_t n, double* __restrict__ sky, double period, double ref,
                                                     int prewound, const int32_t* __restrict__ gate) {
-    if (gate && *gate == 0) return;
+    if (gate && !(gate[0] && gate[1])) return;
     const int row = blockIdx.x;
     const int lane = threadIdx.x;
     double prev = 0.0;
@@ -918,13 +923,14 @@ static int unwind_2xN(int64_t n, double* sky, double period, double ref, hipStre
     int rc = PXL_OK;
     const unsigned g = stream_grid(n, 256);
     hipLaunchKernelGGL(k_unwrap_incr, dim3(g), dim3(256), 0, st, n, (const double*)sky, period, c);
+    if (hipMemsetAsync(flag, 0, 2 * sizeof(int32_t), st) != hipSuccess) rc = fail(PXL_EHIP, "unwind: hipMemsetAsync failed");
     for (int pass = 0; pass < 2 && rc == PXL_OK; ++pass) {
-        if (hipMemsetAsync(flag, 0, sizeof(int32_t), st) != hipSuccess) rc = fail(PXL_EHIP, "unwind: hipMemsetAsync failed");
-        hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nb, 2), dim3(256), 0, st, n, (const int8_t*)c, rloc, bsum, nb);
-        hipLaunchKernelGGL(k_scan_bsums, dim3(2), dim3(1024), 0, st, nb, (const int32_t*)bsum, boff);
+        const int32_t* gate = pass == 0 ? nullptr : flag;        // pass 2 runs on the device only if pass 1 flagged
+        hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nb, 2), dim3(256), 0, st, n, (const int8_t*)c, rloc, bsum, nb, gate);
+        hipLaunchKernelGGL(k_scan_bsums, dim3(2), dim3(1024), 0, st, nb, (const int32_t*)bsum, boff, gate);
         hipLaunchKernelGGL(k_unwrap_verify, dim3(g), dim3(256), 0, st, n, (const double*)sky, period, c,
-                           (const int32_t*)rloc, (const int32_t*)boff, nb, flag);
-        if (rc == PXL_OK) rc = check_launch("k_unwrap scan/verify");
+                           (const int32_t*)rloc, (const int32_t*)boff, nb, flag + pass, gate);
+        rc = check_launch("k_unwrap scan/verify");
     }
     if (rc == PXL_OK) {
         hipLaunchKernelGGL(k_unwrap_apply, dim3(g), dim3(256), 0, st, n, sky, period, ref, (const int32_t*)rloc,
