@@ -1254,7 +1254,7 @@ int pxl_reproject_execute_rows(pxl_reproject_plan* pl, const double* src, double
     // tile height: the configured rh, halved while the launch would leave the chip short of waves
     // (256 CUs x ~16 resident waves, a few rounds each); small maps and thin strips get shorter tiles
     int rh = pl->rh;
-    while (rh > 4 && (int64_t)p.ntx * ((nr + rh - 1) / rh) * pl->nc < 4 * 4096) rh >>= 1;
+    while (rh > 4 && (int64_t)p.ntx * ((nr + rh - 1) / rh) * pl->nc < 16 * 4096) rh >>= 1;
     p.rh = rh;
     p.nty = (int32_t)((nr + rh - 1) / rh);
     p.ntiles = (int64_t)p.ntx * p.nty * pl->nc;
