@@ -69,6 +69,13 @@ int         pxl_device_count(void);
 int pxl_pix2sky_car_f64(const pxl_car_wcs* wcs, int64_t n, const double* pix2xN, double* sky2xN,
                         int wrap_mode, void* stream);
 
+/* ---- rewind!(angles; period, ref_angle)                                            enmap_ops.jl:15-19
+ *      unwind!(angles; dims, period, ref_angle)                                      enmap_ops.jl:26-32
+ *      rewind is elementwise over n doubles.  unwind works along the point axis of an nrow x N column-major
+ *      array (nrow = 2: a 2xN coordinate batch with dims=2; nrow = 1: a plain vector), in place.           */
+int pxl_rewind_f64(double* a, int64_t n, double period, double ref_angle, void* stream);
+int pxl_unwind_f64(double* a, int64_t n, int nrow, double period, double ref_angle, void* stream);
+
 /* ---- pix2sky(shape, wcs, ra_pixel, dec_pixel; safe) broadcast over two N-vectors   car_proj.jl:141-152
  *      safe != 0 -> rewind(ra), rewind(dec).                                                         */
 int pxl_pix2sky_car_soa_f64(const pxl_car_wcs* wcs, int64_t n, const double* ipix, const double* jpix,

@@ -14,8 +14,8 @@ from .geometry import (JlRange, create_car_wcs, fullsky_geometry, geometry, pad_
                        slice_geometry)
 from .enmap import Enmap, NoWCS, getwcs
 from .ops import (ReprojectPlan, fill_random_, fill_sphere_points_, pix2sky, pix2sky_, pix2sky_rewind,
-                  pixareamap, pixareamap_, posmap, reproject, sample_bilinear, sky2pix, sky2pix_,
-                  sky2pix_broadcast)
+                  pixareamap, pixareamap_, posmap, reproject, rewind_, sample_bilinear, sky2pix, sky2pix_,
+                  sky2pix_broadcast, unwind_)
 from .sharding import DecStripReprojector, strip_bounds
 from .fits_io import read_header, read_map, wcs_from_header, write_map
 

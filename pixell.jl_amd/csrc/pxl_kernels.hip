@@ -152,15 +152,14 @@ __global__ __launch_bounds__(256) void k_sky2pix_soa(Sky2Pix s, int64_t n, const
 #define PXL_SCAN_ITEMS 16
 #define PXL_SCAN_BLOCK (256 * PXL_SCAN_ITEMS)
 
-__global__ __launch_bounds__(256) void k_unwrap_incr(int64_t n, const double* __restrict__ m2, double period,
+__global__ __launch_bounds__(256) void k_unwrap_incr(int64_t n, int nrow, const double* __restrict__ m2, double period,
                                                      int8_t* __restrict__ c) {
-    // m2: 2xN interleaved rewound values; c: [2][n]
+    // m2: nrow x N interleaved rewound values (nrow = 2 for coordinate batches, 1 for a plain vector); c: [nrow][n]
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-#pragma unroll
-        for (int row = 0; row < 2; ++row) {
+        for (int row = 0; row < nrow; ++row) {
             int v = 0;
-            if (k > 0) v = (int)rint((m2[2 * k + row] - m2[2 * (k - 1) + row]) / period);
+            if (k > 0) v = (int)rint((m2[nrow * k + row] - m2[nrow * (k - 1) + row]) / period);
             c[row * n + k] = (int8_t)v;
         }
     }
@@ -237,7 +236,7 @@ __device__ inline int32_t scan_value(const int32_t* rloc, const int32_t* boff, i
     return rloc[row * n + k] + boff[row * nb + k / PXL_SCAN_BLOCK];
 }
 
-__global__ __launch_bounds__(256) void k_unwrap_verify(int64_t n, const double* __restrict__ m2, double period,
+__global__ __launch_bounds__(256) void k_unwrap_verify(int64_t n, int nrow, const double* __restrict__ m2, double period,
                                                        int8_t* __restrict__ c, const int32_t* __restrict__ rloc,
                                                        const int32_t* __restrict__ boff, int64_t nb,
                                                        int32_t* __restrict__ flag, const int32_t* __restrict__ gate) {
@@ -245,12 +244,11 @@ __global__ __launch_bounds__(256) void k_unwrap_verify(int64_t n, const double* 
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     bool bad = false;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; k < n; k += stride) {
-#pragma unroll
-        for (int row = 0; row < 2; ++row) {
+        for (int row = 0; row < nrow; ++row) {
             const int32_t rprev = scan_value(rloc, boff, n, nb, row, k - 1);
             const int32_t rk = scan_value(rloc, boff, n, nb, row, k);
-            const double yprev = m2[2 * (k - 1) + row] - (double)rprev * period;     // y[k-1] as the reference forms it
-            const double q = (m2[2 * k + row] - yprev) / period;
+            const double yprev = m2[nrow * (k - 1) + row] - (double)rprev * period;  // y[k-1] as the reference forms it
+            const double q = (m2[nrow * k + row] - yprev) / period;
             if (!isfinite(q)) { bad = true; continue; }       // NaN/Inf poison everything after them: serial path
             const int32_t t = (int32_t)rint(q);
             if (t != rk) {
@@ -262,27 +260,33 @@ __global__ __launch_bounds__(256) void k_unwrap_verify(int64_t n, const double* 
     if (bad) atomicOr(flag, 1);
 }
 
-__global__ __launch_bounds__(256) void k_unwrap_apply(int64_t n, double* __restrict__ m2, double period, double ref,
+__global__ __launch_bounds__(256) void k_unwrap_apply(int64_t n, int nrow, double* __restrict__ m2, double period, double ref,
                                                       const int32_t* __restrict__ rloc, const int32_t* __restrict__ boff,
                                                       int64_t nb, const int32_t* __restrict__ flag) {
     // flag[0]: pass 1 found mismatches; flag[1]: pass 2 (run only then) still found some
     if (flag[0] && flag[1]) return;         // unverified: the serial kernel produces the answer
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-        double2 m = *reinterpret_cast<const double2*>(m2 + 2 * k);
-        double y0 = m.x, y1 = m.y;
-        if (k > 0) {
-            y0 = m.x - (double)scan_value(rloc, boff, n, nb, 0, k) * period;
-            y1 = m.y - (double)scan_value(rloc, boff, n, nb, 1, k) * period;
+        if (nrow == 2) {
+            double2 m = *reinterpret_cast<const double2*>(m2 + 2 * k);
+            double y0 = m.x, y1 = m.y;
+            if (k > 0) {
+                y0 = m.x - (double)scan_value(rloc, boff, n, nb, 0, k) * period;
+                y1 = m.y - (double)scan_value(rloc, boff, n, nb, 1, k) * period;
+            }
+            *reinterpret_cast<double2*>(m2 + 2 * k) = make_double2(y0 + ref, y1 + ref);
+        } else {
+            double y = m2[k];
+            if (k > 0) y = y - (double)scan_value(rloc, boff, n, nb, 0, k) * period;
+            m2[k] = y + ref;
         }
-        *reinterpret_cast<double2*>(m2 + 2 * k) = make_double2(y0 + ref, y1 + ref);
     }
 }
 
 // Exact serial form (one wave per coordinate row, 64 dependent steps per 64 points): the fallback when the
 // speculative scan cannot be verified, and the whole algorithm for tiny batches.  `prewound` = input already
 // holds m = rewind(.) - ref.  gate: run only if *gate != 0 (NULL = always).
-__global__ __launch_bounds__(64) void k_unwind_rows(int64_t n, double* __restrict__ sky, double period, double ref,
+__global__ __launch_bounds__(64) void k_unwind_rows(int64_t n, int nrow, double* __restrict__ sky, double period, double ref,
                                                     int prewound, const int32_t* __restrict__ gate) {
     if (gate && !(gate[0] && gate[1])) return;
     const int row = blockIdx.x;
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(64) void k_unwind_rows(int64_t n, double* __restric
     for (int64_t base = 0; base < n; base += 64) {
         int64_t k = base + lane;
         double m = 0.0;
-        if (k < n) m = prewound ? sky[2 * k + row] : rewind(sky[2 * k + row], period, ref) - ref;
+        if (k < n) m = prewound ? sky[nrow * k + row] : rewind(sky[nrow * k + row], period, ref) - ref;
         double y = m;
         int cnt = (int)((n - base) < 64 ? (n - base) : 64);
         for (int l = 0; l < cnt; ++l) {
@@ -302,7 +306,24 @@ __global__ __launch_bounds__(64) void k_unwind_rows(int64_t n, double* __restric
             have_prev = true;
             if (lane == l) y = yl;
         }
-        if (k < n) sky[2 * k + row] = y + ref;
+        if (k < n) sky[nrow * k + row] = y + ref;
+    }
+}
+
+// rewind! on a flat array (enmap_ops.jl:15-19); sub_ref: also subtract ref (first half of unwind!)
+__global__ __launch_bounds__(256) void k_rewind(int64_t n, double* a, double period, double ref, int sub_ref) {
+    const int64_t chunk = (int64_t)blockDim.x * 4;
+    for (int64_t k0 = (int64_t)blockIdx.x * chunk + threadIdx.x; k0 < n; k0 += (int64_t)gridDim.x * chunk) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { int64_t k = k0 + u * blockDim.x; v[u] = (k < n) ? a[k] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int64_t k = k0 + u * blockDim.x;
+            double r = rewind(v[u], period, ref);
+            if (sub_ref) r = r - ref;
+            if (k < n) a[k] = r;
+        }
     }
 }
 
@@ -901,14 +922,14 @@ struct pxl_reproject_plan {
 
 // unwind!(sky2xN; dims=2) on a buffer that already holds m = rewind(.) - ref (see k_unwrap_* above).
 // Scratch comes from the stream-ordered allocator (hipMallocAsync / hipFreeAsync): no host synchronisation.
-static int unwind_2xN(int64_t n, double* sky, double period, double ref, hipStream_t st) {
+static int unwind_rows(int64_t n, int nrow, double* sky, double period, double ref, hipStream_t st) {
     if (n <= 4096) {       // tiny batches: the exact serial kernel is already fast enough
-        hipLaunchKernelGGL(k_unwind_rows, dim3(2), dim3(64), 0, st, n, sky, period, ref, 1, (const int32_t*)nullptr);
+        hipLaunchKernelGGL(k_unwind_rows, dim3(nrow), dim3(64), 0, st, n, nrow, sky, period, ref, 1, (const int32_t*)nullptr);
         return check_launch("k_unwind_rows");
     }
     const int64_t nb = (n + PXL_SCAN_BLOCK - 1) / PXL_SCAN_BLOCK;
     if (nb > 0x7fffffffLL) return fail(PXL_EINVAL, "unwind: batch too long");
-    const size_t bytes_c = (size_t)2 * n, bytes_r = (size_t)8 * n, bytes_b = (size_t)8 * nb;
+    const size_t bytes_c = (size_t)nrow * n, bytes_r = (size_t)4 * nrow * n, bytes_b = (size_t)4 * nrow * nb;
     const size_t off_r = (bytes_c + 255) & ~(size_t)255;
     const size_t off_bs = off_r + ((bytes_r + 255) & ~(size_t)255);
     const size_t off_bo = off_bs + ((bytes_b + 255) & ~(size_t)255);
@@ -922,20 +943,20 @@ static int unwind_2xN(int64_t n, double* sky, double period, double ref, hipStre
     int32_t* flag = (int32_t*)(ws + off_fl);
     int rc = PXL_OK;
     const unsigned g = stream_grid(n, 256);
-    hipLaunchKernelGGL(k_unwrap_incr, dim3(g), dim3(256), 0, st, n, (const double*)sky, period, c);
+    hipLaunchKernelGGL(k_unwrap_incr, dim3(g), dim3(256), 0, st, n, nrow, (const double*)sky, period, c);
     if (hipMemsetAsync(flag, 0, 2 * sizeof(int32_t), st) != hipSuccess) rc = fail(PXL_EHIP, "unwind: hipMemsetAsync failed");
     for (int pass = 0; pass < 2 && rc == PXL_OK; ++pass) {
         const int32_t* gate = pass == 0 ? nullptr : flag;        // pass 2 runs on the device only if pass 1 flagged
-        hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nb, 2), dim3(256), 0, st, n, (const int8_t*)c, rloc, bsum, nb, gate);
-        hipLaunchKernelGGL(k_scan_bsums, dim3(2), dim3(1024), 0, st, nb, (const int32_t*)bsum, boff, gate);
-        hipLaunchKernelGGL(k_unwrap_verify, dim3(g), dim3(256), 0, st, n, (const double*)sky, period, c,
+        hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nb, nrow), dim3(256), 0, st, n, (const int8_t*)c, rloc, bsum, nb, gate);
+        hipLaunchKernelGGL(k_scan_bsums, dim3(nrow), dim3(1024), 0, st, nb, (const int32_t*)bsum, boff, gate);
+        hipLaunchKernelGGL(k_unwrap_verify, dim3(g), dim3(256), 0, st, n, nrow, (const double*)sky, period, c,
                            (const int32_t*)rloc, (const int32_t*)boff, nb, flag + pass, gate);
         rc = check_launch("k_unwrap scan/verify");
     }
     if (rc == PXL_OK) {
-        hipLaunchKernelGGL(k_unwrap_apply, dim3(g), dim3(256), 0, st, n, sky, period, ref, (const int32_t*)rloc,
+        hipLaunchKernelGGL(k_unwrap_apply, dim3(g), dim3(256), 0, st, n, nrow, sky, period, ref, (const int32_t*)rloc,
                            (const int32_t*)boff, nb, (const int32_t*)flag);
-        hipLaunchKernelGGL(k_unwind_rows, dim3(2), dim3(64), 0, st, n, sky, period, ref, 1, (const int32_t*)flag);
+        hipLaunchKernelGGL(k_unwind_rows, dim3(nrow), dim3(64), 0, st, n, nrow, sky, period, ref, 1, (const int32_t*)flag);
         rc = check_launch("k_unwrap_apply");
     }
     hipError_t e = hipFreeAsync(ws, st);
@@ -978,7 +999,28 @@ int pxl_pix2sky_car_f64(const pxl_car_wcs* wcs, int64_t n, const double* pix, do
                        (const double2*)pix, (double2*)sky, mode);
     int rc = check_launch("k_pix2sky_pairs");
     if (rc || wrap_mode != PXL_WRAP_UNWIND) return rc;
-    return unwind_2xN(n, sky, PXL_TWOPI_D, 0.0, st);
+    return unwind_rows(n, 2, sky, PXL_TWOPI_D, 0.0, st);
+}
+
+int pxl_rewind_f64(double* a, int64_t n, double period, double ref_angle, void* stream) {
+    if (n < 0 || (n > 0 && !a)) return fail(PXL_EINVAL, "rewind: null buffer or negative n");
+    if (!(period > 0.0) || !std::isfinite(period) || !std::isfinite(ref_angle)) return fail(PXL_EINVAL, "rewind: period must be positive and finite");
+    if (n == 0) return PXL_OK;
+    hipLaunchKernelGGL(k_rewind, dim3(stream_grid((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, n, a, period, ref_angle, 0);
+    return check_launch("k_rewind");
+}
+
+int pxl_unwind_f64(double* a, int64_t n, int nrow, double period, double ref_angle, void* stream) {
+    if (n < 0 || (n > 0 && !a)) return fail(PXL_EINVAL, "unwind: null buffer or negative n");
+    if (nrow != 1 && nrow != 2) return fail(PXL_EINVAL, "unwind: nrow must be 1 (vector) or 2 (2xN batch)");
+    if (!(period > 0.0) || !std::isfinite(period) || !std::isfinite(ref_angle)) return fail(PXL_EINVAL, "unwind: period must be positive and finite");
+    if (nrow == 2 && ((uintptr_t)a & 15) != 0) return fail(PXL_EINVAL, "unwind: 2xN buffer must be 16-byte aligned");
+    if (n == 0) return PXL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_rewind, dim3(stream_grid(((int64_t)nrow * n + 3) / 4, 256)), dim3(256), 0, st, (int64_t)nrow * n, a, period, ref_angle, 1);
+    int rc = check_launch("k_rewind");
+    if (rc) return rc;
+    return unwind_rows(n, nrow, a, period, ref_angle, st);
 }
 
 int pxl_pix2sky_car_soa_f64(const pxl_car_wcs* wcs, int64_t n, const double* ipix, const double* jpix,

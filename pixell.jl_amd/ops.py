@@ -111,6 +111,30 @@ def pix2sky_rewind(m, pixcoords):
     return sky
 
 
+# ---- rewind / unwind on device arrays (enmap_ops.jl:10-32) ----------------------------------------
+
+def rewind_(angles: torch.Tensor, period=2 * 3.141592653589793, ref_angle=0.0):
+    """rewind!(angles; period, ref_angle), elementwise, in place."""
+    a = _dev_f64(angles, "angles")
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().pxl_rewind_f64(_ptr(a), a.numel(), float(period), float(ref_angle), _stream(a)))
+    return angles
+
+
+def unwind_(angles: torch.Tensor, period=2 * 3.141592653589793, ref_angle=0.0):
+    """unwind!(angles; dims=2, ...) for an (N, 2) coordinate batch, or along a 1-D vector; in place."""
+    a = _dev_f64(angles, "angles")
+    if a.dim() == 2 and a.shape[1] == 2:
+        n, nrow = a.shape[0], 2
+    elif a.dim() == 1:
+        n, nrow = a.shape[0], 1
+    else:
+        raise ValueError("unwind_ takes an (N, 2) batch or a 1-D vector")
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().pxl_unwind_f64(_ptr(a), n, nrow, float(period), float(ref_angle), _stream(a)))
+    return angles
+
+
 # ---- sky2pix ------------------------------------------------------------------------------------
 
 def sky2pix_(m, skycoords, pixcoords, safe=True):

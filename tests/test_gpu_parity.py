@@ -540,3 +540,24 @@ def test_generic_reproject_car_tan(pj, O, dev, literals):
     exp = O.reproject(fs[1], fs[0], src, fs2[1], fs2[0])
     gen = O.reproject_generic(fs[1], 0, (fs[0][0], fs[0][1], 1), src, fs2[1], 0, fs2[0])
     assert bits_equal(gen, exp)
+
+
+def test_rewind_and_unwind_entries(pj, O, dev):
+    """Standalone rewind! / unwind! (enmap_ops.jl:15-32) with the periods and reference angles the reference
+    itself uses: 2*pi about 0 for angles, the pixel period about the map centre for sky2pix."""
+    rng = np.random.default_rng(31)
+    a = rng.uniform(-80, 80, 100001)
+    for period, ref in ((2 * math.pi, 0.0), (360.0, 181.0), (43200.000000000007, 21601.0)):
+        got = pj.rewind_(to_dev(a * (period / 6.0), dev), period, ref).cpu().numpy()
+        exp = np.array([O.rewind(v, period, ref) for v in a * (period / 6.0)])
+        assert bits_equal(got, exp), (period, ref)
+    walk = np.cumsum(rng.normal(0, 2.0, 300000)) + 11.0
+    for period, ref in ((2 * math.pi, 0.0), (5.0, 1.25)):
+        got = pj.unwind_(to_dev(walk, dev), period, ref).cpu().numpy()          # 1-D vector
+        assert bits_equal(got, O.unwind_row(walk, period, ref)), (period, ref)
+        two = np.stack([walk, -0.5 * walk[::-1]], axis=1)
+        got = pj.unwind_(to_dev(two, dev), period, ref).cpu().numpy()           # 2xN batch, dims=2
+        exp = np.stack([O.unwind_row(two[:, 0], period, ref), O.unwind_row(two[:, 1], period, ref)], axis=1)
+        assert bits_equal(got, exp), (period, ref)
+    short = rng.uniform(-20, 20, 100)
+    assert bits_equal(pj.unwind_(to_dev(short, dev)).cpu().numpy(), O.unwind_row(short))
