@@ -2,7 +2,7 @@
 """bench.py -- headline benchmark: Float64 CAR bilinear reprojection throughput (Mpix/s) and fraction of
 the MI355X HBM roofline, at 1/2/4/8 GPUs of one node (strong scaling, dec-strip sharding, RCCL halo).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg3|cfg2|cfg5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg4x2|cfg3|cfg2|cfg5]
 
 For N > 1 launch one rank per GPU:
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -53,6 +53,10 @@ def workload_geometry(name):
         shape_out = shape_in[:2]
         wcs_out = pj.CarClenshawCurtis(wcs_in.cdelt, (wcs_in.crpix[0] + 0.5, wcs_in.crpix[1] + 0.5), wcs_in.crval)
         desc = "cfg4: 43200x21601x3 IQU Float64 full-sky CAR -> same shape, half-pixel-shifted WCS (0.5 arcmin)"
+    elif name == "cfg4x2":      # SURVEY 8(d) "secondary": the IQU map onto the 2x-refined grid (89.6 GB out)
+        shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 43200, dims=(3,))
+        shape_out, wcs_out = pj.fullsky_geometry(2 * math.pi / 86400)
+        desc = "cfg4x2: 43200x21601x3 IQU Float64 full-sky CAR -> 2x-refined 86400x43201x3 (0.25 arcmin)"
     elif name == "cfg3":
         shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 21600)
         shape_out, wcs_out = pj.fullsky_geometry(2 * math.pi / 43200)
