@@ -312,3 +312,32 @@ def test_unwind_agrees_with_numpy_unwrap(O):
     ref = np.unwrap(wound)
     assert np.max(np.abs(ours - ref)) < 1e-9
     assert np.array_equal(np.round((ours - wound) / (2 * math.pi)), np.round((ref - wound) / (2 * math.pi)))
+
+
+def _golden():
+    import json
+    with open(os.path.join(GOLDEN, "oracle_golden.json")) as f:
+        return json.load(f)
+
+
+def test_oracle_reproduces_its_frozen_outputs(O):
+    """Guards the (unpinned) definition of R1 and the evaluators against silent drift of the oracle itself."""
+    g = _golden()
+    shape, w = O.fullsky_geometry(2 * math.pi / 64)
+    nx, ny = shape
+    assert list(shape) == g["geometry"]["shape"] and list(w.crpix) == g["geometry"]["crpix"]
+    jj, ii = np.meshgrid(np.arange(1, ny + 1, dtype=float), np.arange(1, nx + 1, dtype=float), indexing="ij")
+    src = (((jj - 1) * nx + ii) ** 2)[None]
+    shape2, w2 = O.fullsky_geometry(2 * math.pi / 128)
+
+    class Shift:
+        cdelt, crval, unit = tuple(w.cdelt), tuple(w.crval), w.unit
+        crpix = (w.crpix[0] + 0.5, w.crpix[1] + 0.5)
+    assert bits_equal(O.reproject(w, (nx, ny, 1), src, w2, shape2).ravel(), unhex(g["refined"], 1).ravel())
+    assert bits_equal(O.reproject(w, (nx, ny, 1), src, Shift, shape).ravel(), unhex(g["shifted"], 1).ravel())
+    pix = unhex(g["pix"])
+    assert bits_equal(O.pix2sky(w, pix, O.WRAP_NONE), unhex(g["pix2sky_unsafe"]))
+    assert bits_equal(O.pix2sky(w, pix, O.WRAP_REWIND), unhex(g["pix2sky_rewind"]))
+    assert bits_equal(O.pix2sky(w, pix, O.WRAP_UNWIND), unhex(g["pix2sky_unwind"]))
+    sky = unhex(g["pix2sky_unsafe"])
+    assert bits_equal(O.sky2pix(w, shape, sky, safe=True, form=O.FORM_RECIP), unhex(g["sky2pix_safe_recip"]))
