@@ -65,6 +65,11 @@ def workload_geometry(name):
         shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 4096)
         shape_out, wcs_out = pj.fullsky_geometry(2 * math.pi / 8192)
         desc = "cfg2: 4096x2049 Float64 full-sky CAR -> 2x-refined 8192x4097 (cache resident)"
+    elif name in ("down2", "down4", "up4"):     # other scale factors (diagnostics; not BASELINE configs)
+        nin, nout = {"down2": (43200, 21600), "down4": (43200, 10800), "up4": (10800, 43200)}[name]
+        shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / nin)
+        shape_out, wcs_out = pj.fullsky_geometry(2 * math.pi / nout)
+        desc = "%s: %dx%d -> %dx%d" % (name, shape_in[0], shape_in[1], shape_out[0], shape_out[1])
     else:
         raise ValueError(name)
     nc = shape_in[2] if len(shape_in) > 2 else 1

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpixell_hip.so")
+LIB_PATH = os.environ.get("PXL_LIB_PATH", os.path.join(_HERE, "libpixell_hip.so"))   # override: A/B builds
 
 WRAP_NONE, WRAP_REWIND, WRAP_UNWIND = 0, 1, 2
 FORM_RECIP, FORM_DIV, FORM_RECIP_AV = 0, 1, 2

@@ -238,7 +238,7 @@ static int launch_reproject_dma(int pairs, int nch, dim3 grid, size_t lds_bytes,
     if (pairs == P && nch == N) { hipLaunchKernelGGL((k_reproject_dma<P, N>), grid, dim3(64), lds_bytes, st, p); return check_launch("k_reproject_dma"); }
     PXL_DMA_CASE(1, 1) PXL_DMA_CASE(1, 2) PXL_DMA_CASE(1, 3) PXL_DMA_CASE(1, 4) PXL_DMA_CASE(1, 5)
     PXL_DMA_CASE(2, 1) PXL_DMA_CASE(2, 2) PXL_DMA_CASE(2, 3) PXL_DMA_CASE(2, 4) PXL_DMA_CASE(2, 5)
-    PXL_DMA_CASE(4, 2) PXL_DMA_CASE(4, 3) PXL_DMA_CASE(4, 4) PXL_DMA_CASE(4, 5)
+    PXL_DMA_CASE(4, 1) PXL_DMA_CASE(4, 2) PXL_DMA_CASE(4, 3) PXL_DMA_CASE(4, 4) PXL_DMA_CASE(4, 5)
 #undef PXL_DMA_CASE
     return fail(PXL_EINVAL, "reproject: no LDS-DMA kernel for pairs=%d nch=%d", pairs, nch);
 }
