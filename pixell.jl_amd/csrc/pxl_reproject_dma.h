@@ -29,25 +29,17 @@ __device__ __forceinline__ void wait_vm() {
 // wait until the DMA of the row that is `k` rows older than the newest requested row has landed
 template <int NCH>
 __device__ __forceinline__ void wait_rows(int k) {
-    constexpr int C = (63 / NCH);          // vmcnt saturates at 63
-    if (k > C) k = C;
-    switch (k) {
+    // k = rows requested after the one needed.  Rounding k down is always safe (a stricter wait), so clamp to
+    // 7: eight cases compile to a three-level branch tree instead of sixteen.
+    switch (k > 7 ? 7 : k) {
         case 0: wait_vm<0>(); break;
-        case 1: wait_vm<(1 * NCH > 63 ? 63 : 1 * NCH)>(); break;
-        case 2: wait_vm<(2 * NCH > 63 ? 63 : 2 * NCH)>(); break;
-        case 3: wait_vm<(3 * NCH > 63 ? 63 : 3 * NCH)>(); break;
-        case 4: wait_vm<(4 * NCH > 63 ? 63 : 4 * NCH)>(); break;
-        case 5: wait_vm<(5 * NCH > 63 ? 63 : 5 * NCH)>(); break;
-        case 6: wait_vm<(6 * NCH > 63 ? 63 : 6 * NCH)>(); break;
-        case 7: wait_vm<(7 * NCH > 63 ? 63 : 7 * NCH)>(); break;
-        case 8: wait_vm<(8 * NCH > 63 ? 63 : 8 * NCH)>(); break;
-        case 9: wait_vm<(9 * NCH > 63 ? 63 : 9 * NCH)>(); break;
-        case 10: wait_vm<(10 * NCH > 63 ? 63 : 10 * NCH)>(); break;
-        case 11: wait_vm<(11 * NCH > 63 ? 63 : 11 * NCH)>(); break;
-        case 12: wait_vm<(12 * NCH > 63 ? 63 : 12 * NCH)>(); break;
-        case 13: wait_vm<(13 * NCH > 63 ? 63 : 13 * NCH)>(); break;
-        case 14: wait_vm<(14 * NCH > 63 ? 63 : 14 * NCH)>(); break;
-        default: wait_vm<(15 * NCH > 63 ? 63 : 15 * NCH)>(); break;     // k >= 15: rounding down is safe
+        case 1: wait_vm<1 * NCH>(); break;
+        case 2: wait_vm<2 * NCH>(); break;
+        case 3: wait_vm<3 * NCH>(); break;
+        case 4: wait_vm<4 * NCH>(); break;
+        case 5: wait_vm<5 * NCH>(); break;
+        case 6: wait_vm<6 * NCH>(); break;
+        default: wait_vm<7 * NCH>(); break;
     }
 }
 
@@ -145,7 +137,6 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
     // ---- per-lane source byte offsets of each 1-KiB chunk within a source row (constant over the tile);
     //      0xFFFFFFFF marks a column outside a non-periodic map
     uint32_t voff[NCH];
-    bool chunk_in[NCH];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         int64_t u = cbase0 + ch * 128 + 2 * lane;
@@ -153,44 +144,57 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
         if (p.periodic) { u %= p.nx; if (u < 0) u += p.nx; }
         else ok = (u >= 0) && (u < p.nx);
         voff[ch] = ok ? (uint32_t)(u * 8) : 0xFFFFFFFFu;
-        chunk_in[ch] = (ch * 128 + 2 * lane) < p.seg;           // tail chunk: lanes past the slot end stay out
     }
 
     const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
     const uint32_t slot_bytes = (uint32_t)p.seg * 8u;
     const int ns_mask = p.ns - 1;
-    const bool skip_loads = (p.flags & 1) != 0;
 
-    auto issue_row = [&](int tt) {      // request source row j = dir * tt into slot tt & ns_mask
-        const int j = dir * tt;
-        const int64_t jr = (int64_t)j - 1 - p.src_row0;
-        const bool row_ok = (j >= 1) && (j <= p.ny) && (jr >= 0) && (jr < p.src_nrows) && !skip_loads;
-        const uint32_t slot_addr = lds_base + (uint32_t)(tt & ns_mask) * slot_bytes;
+    // ---- request bookkeeping (all wave-uniform).  Rows are requested strictly in t order, so the row
+    // pointer advances by a constant stride and validity is a range test in t space.
+    int tv_lo = 1, tv_hi = 0;                                   // valid t range (empty by default)
+    {
+        const int64_t jlo = (p.src_row0 + 1 > 1) ? p.src_row0 + 1 : 1;                    // first resident in-map row
+        const int64_t jhi = (p.src_row0 + p.src_nrows < p.ny) ? p.src_row0 + p.src_nrows : p.ny;
+        if (jhi >= jlo && !(p.flags & 1)) {
+            if (p.dypos) { tv_lo = (int)jlo; tv_hi = (int)jhi; } else { tv_lo = -(int)jhi; tv_hi = -(int)jlo; }
+        }
+    }
+    const int64_t row_step = (int64_t)dir * p.nx * 8;           // bytes from row t to row t + 1
+    int treq = __builtin_amdgcn_readlane(my_t0, 0) - 1;         // nothing requested yet
+    const char* next_row = (const char*)splane + ((int64_t)dir * (treq + 1) - 1 - p.src_row0) * p.nx * 8;
+    const bool tail_full = (p.seg == NCH * 128);
+    const bool in_tail = ((NCH - 1) * 128 + 2 * lane) < p.seg;  // lanes of the last chunk inside the slot
+    const uint32_t zero_off = 0u;
+
+    auto issue_next = [&]() {           // request source row t = treq + 1 into slot t & ns_mask
+        ++treq;
+        const bool valid = (treq >= tv_lo) && (treq <= tv_hi);
+        const uint32_t slot_addr = lds_base + (uint32_t)(treq & ns_mask) * slot_bytes;
         if (p.periodic) {
-            // every lane has a valid column: SGPR row base + 32-bit per-lane offset
-            const double* rowp = row_ok ? splane + jr * p.nx : p.zero_page;
+            // every lane has a valid column: SGPR row base + 32-bit per-lane byte offset
+            const void* base = valid ? (const void*)next_row : (const void*)p.zero_page;
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
-                const uint32_t off = row_ok ? voff[ch] : 0u;
-                if ((ch + 1) * 128 <= p.seg) glds16_saddr(rowp, off, slot_addr + ch * 1024u);
-                else if (chunk_in[ch]) glds16_saddr(rowp, off, slot_addr + ch * 1024u);   // lane 0 is always in
+                const uint32_t off = valid ? voff[ch] : zero_off;
+                if (ch < NCH - 1 || tail_full) glds16_saddr(base, off, slot_addr + ch * 1024u);
+                else if (in_tail) glds16_saddr(base, off, slot_addr + ch * 1024u);        // lane 0 is always in
             }
         } else {
-            const double* rowp = splane + (row_ok ? jr : 0) * p.nx;
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
-                const void* g = (row_ok && voff[ch] != 0xFFFFFFFFu)
-                                    ? (const void*)((const char*)rowp + voff[ch]) : (const void*)p.zero_page;
-                if ((ch + 1) * 128 <= p.seg) glds16_vaddr(g, slot_addr + ch * 1024u);
-                else if (chunk_in[ch]) glds16_vaddr(g, slot_addr + ch * 1024u);
+                const void* g = (valid && voff[ch] != 0xFFFFFFFFu) ? (const void*)(next_row + voff[ch])
+                                                                   : (const void*)p.zero_page;
+                if (ch < NCH - 1 || tail_full) glds16_vaddr(g, slot_addr + ch * 1024u);
+                else if (in_tail) glds16_vaddr(g, slot_addr + ch * 1024u);
             }
         }
+        next_row += row_step;
     };
 
     const bool vec_store = ((p.nxo & 1) == 0) && (((uintptr_t)p.dst & 15) == 0);
     double* orow = dplane + rb * p.nxo + c0 + 2 * lane;        // this lane's first output pair in row rb
 
-    int treq = __builtin_amdgcn_readlane(my_t0, 0) - 1;        // nothing requested yet
     for (int rr = 0; rr < nrows; ++rr) {
         const int t0 = __builtin_amdgcn_readlane(my_t0, rr);
         const double fy = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_fy), rr),
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
             int tmax = __builtin_amdgcn_readlane(my_t0, ra) + 1;
             const int tlim = t0 + p.ns - 1;
             if (tmax > tlim) tmax = tlim;
-            while (treq < tmax) { ++treq; issue_row(treq); }
+            while (treq < tmax) issue_next();
         }
         wait_rows<NCH>(treq - (t0 + 1));
 
