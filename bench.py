@@ -243,9 +243,9 @@ def bench_reproject(args, rank, world, dev):
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": desc, "shape_in": list(shape_in), "shape_out": list(shape_out) + [nc],
                    "parallelism": "dec-strip x%d, %d-row halo via %s send/recv" % (
-                       world, max([hi - lo for _, lo, hi in sh.recvs], default=0),
+                       world, max([hi - lo for _, lo, hi in sh.recvs + sh.sends], default=0),
                        "RCCL" if (world == 1 or dist.get_backend() == "nccl") else "gloo (host-staged REHEARSAL)"),
-                   "halo_bytes_per_rank": sh.halo_bytes(),
+                   "halo_bytes_per_message": max([(hi - lo) * nx * nc * 8 for _, lo, hi in sh.recvs + sh.sends], default=0),
                    "bytes_per_output_value": round(8.0 * (nx * ny + nxo * nyo) / (nxo * nyo), 3)},
         "roofline": {"bound": "hbm", "kernel": "k_reproject_dma",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
