@@ -73,3 +73,18 @@ def test_product_never_touches_the_oracle():
     # the shared library has no dependency on liboracle
     out = subprocess.run(["ldd", os.path.join(PKG, "libpixell_hip.so")], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_header_is_plain_c_and_links(tmp_path, pj):
+    """include/pixell_hip.h compiles as C99 and a C program links against the shared library and runs its
+    no-GPU paths (gcc, no hipcc, no C++)."""
+    exe = str(tmp_path / "abi_c99")
+    libdir = os.path.dirname(pj.library_path())
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c", "abi_c99.c"), "-o", exe, "-L", libdir, "-lpixell_hip",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "abi_c99 ok" in r.stdout
