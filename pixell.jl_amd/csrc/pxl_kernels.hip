@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void k_unwrap_incr(int64_t n, int nrow, const 
 }
 
 // local inclusive scan of 4096-element blocks; blockIdx.y = coordinate row
-__global__ __launch_bounds__(256) void k_scan_local(int64_t n, const int8_t* __restrict__ c, int32_t* __restrict__ rloc,
+template <typename TIN>
+__global__ __launch_bounds__(256) void k_scan_local(int64_t n, const TIN* __restrict__ c, int32_t* __restrict__ rloc,
                                                     int32_t* __restrict__ bsum, int64_t nb, const int32_t* __restrict__ gate) {
     __shared__ int32_t wsum[4];
     if (gate && *gate == 0) return;         // second pass: only if the first verification found mismatches
@@ -947,7 +948,7 @@ static int unwind_rows(int64_t n, int nrow, double* sky, double period, double r
     if (hipMemsetAsync(flag, 0, 2 * sizeof(int32_t), st) != hipSuccess) rc = fail(PXL_EHIP, "unwind: hipMemsetAsync failed");
     for (int pass = 0; pass < 2 && rc == PXL_OK; ++pass) {
         const int32_t* gate = pass == 0 ? nullptr : flag;        // pass 2 runs on the device only if pass 1 flagged
-        hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nb, nrow), dim3(256), 0, st, n, (const int8_t*)c, rloc, bsum, nb, gate);
+        hipLaunchKernelGGL((k_scan_local<int8_t>), dim3((unsigned)nb, nrow), dim3(256), 0, st, n, (const int8_t*)c, rloc, bsum, nb, gate);
         hipLaunchKernelGGL(k_scan_bsums, dim3(nrow), dim3(1024), 0, st, nb, (const int32_t*)bsum, boff, gate);
         hipLaunchKernelGGL(k_unwrap_verify, dim3(g), dim3(256), 0, st, n, nrow, (const double*)sky, period, c,
                            (const int32_t*)rloc, (const int32_t*)boff, nb, flag + pass, gate);
@@ -1419,9 +1420,9 @@ int pxl_sample_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shape_i
     if (n == 0) return PXL_OK;
     Sky2Pix s = sky2pix_setup(*wcs_in, shape_in[0], shape_in[1], 1, PXL_FORM_RECIP);
     int periodic = fabs((double)shape_in[0] * fabs(wcs_in->cdelt[0] * wcs_in->unit) - PXL_TWOPI_D) < 1e-8;
-    hipLaunchKernelGGL(k_sample_bilinear, dim3(stream_grid((n + PXL_SUNR - 1) / PXL_SUNR, 256)), dim3(256), 0, (hipStream_t)stream, s, src,
-                       shape_in[0], shape_in[1], (int32_t)shape_in[2], src_row0, src_nrows, periodic, n,
-                       (const double2*)sky, out);
+    hipLaunchKernelGGL(k_sample_bilinear, dim3(stream_grid((n + PXL_SUNR - 1) / PXL_SUNR, 256)), dim3(256), 0,
+                       (hipStream_t)stream, s, src, shape_in[0], shape_in[1], (int32_t)shape_in[2], src_row0, src_nrows,
+                       periodic, n, (const double2*)sky, out);
     return check_launch("k_sample_bilinear");
 }
 

@@ -586,3 +586,4 @@ def test_device_matches_frozen_golden(pj, dev):
     assert bits_equal(pj.sky2pix(m, sky, safe=True).cpu().numpy(), unhex(g["sky2pix_safe_recip"]))
     x, y = pj.sky2pix_broadcast(m, sky[:, 0].contiguous(), sky[:, 1].contiguous(), safe=True)
     assert bits_equal(torch.stack([x, y], dim=1).cpu().numpy(), unhex(g["sky2pix_safe_div"]))
+
