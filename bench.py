@@ -255,8 +255,16 @@ def bench_reproject(args, rank, world, dev):
                      "kernel_ms_avg": round(k_avg_ms, 4), "kernel_ms_min": round(kms[0], 4),
                      "kernel_ms_median": round(kms[len(kms) // 2], 4)},
     }
-    if args.check and rank == 0:
-        result["check"] = spot_check(sh, src, dst, shape_in, wcs_in, shape_out, wcs_out)
+    if args.check:
+        # every rank checks rows of its own strip (row 0 of a strip is the one that needs the halo) and the
+        # worst case is reported
+        chk = spot_check(sh, src, dst, shape_in, wcs_in, shape_out, wcs_out)
+        if world > 1:
+            on = dev if dist.get_backend() == "nccl" else "cpu"
+            t = torch.tensor([chk["max_abs_err"], 0.0 if chk["bit_identical"] else 1.0], dtype=torch.float64, device=on)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            chk = {"max_abs_err": float(t[0]), "bit_identical": bool(t[1] == 0.0), "ranks_checked": world}
+        result["check"] = chk
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         del src, dst
         torch.cuda.empty_cache()
