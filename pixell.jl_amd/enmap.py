@@ -81,14 +81,23 @@ class Enmap:
         return self.data[idx]
 
     def getindex(self, sel_x=None, sel_y=None, sel_c=None):
-        """m[sel_x, sel_y] with copy semantics; supports negative steps (test_enmap.jl:17-31)."""
+        """m[sel_x, sel_y] with copy semantics; supports negative steps (test_enmap.jl:17-31).
+        Built from basic strided slices + flip + one contiguous copy (TensorIterator paths, which split
+        operands beyond 32-bit indexing); torch's gather-style kernels (index_select, advanced indexing)
+        were observed to return wrong data for operands above ~1.9 GB on this ROCm build."""
         rx, ry = _as_range(sel_x, self.shape[0]), _as_range(sel_y, self.shape[1])
-        ix = torch.arange(rx.first - 1, rx.last - 1 + (1 if rx.step > 0 else -1), rx.step, device=self.data.device)
-        iy = torch.arange(ry.first - 1, ry.last - 1 + (1 if ry.step > 0 else -1), ry.step, device=self.data.device)
-        d = self.data.index_select(-1, ix).index_select(-2, iy)
+
+        def cut(t, r, dim):
+            if r.length == 0:
+                return t.narrow(dim, 0, 0)
+            lo, hi = (r.first, r.last) if r.step > 0 else (r.last, r.first)       # 1-based inclusive, ascending
+            idx = [slice(None)] * t.dim()
+            idx[dim] = slice(lo - 1, hi, abs(r.step))
+            t = t[tuple(idx)]
+            return torch.flip(t, dims=[dim]) if r.step < 0 else t
+        d = cut(cut(self.data, rx, -1), ry, -2)
         if sel_c is not None and self.data.dim() == 3:
-            rc = _as_range(sel_c, self.data.shape[0])
-            d = d[rc.to_slice()]
+            d = cut(d, _as_range(sel_c, self.data.shape[0]), 0)
         _, new_wcs = slice_geometry(self.shape, self.wcs, rx, ry)
         return Enmap(d.contiguous(), new_wcs)
 

@@ -132,3 +132,25 @@ def test_config5_scattered_sample_properties(pj, O, dev):
     assert bits_equal(out[:, idx].cpu().numpy(), exp)
     m.data.fill_(3.25)
     assert float((pj.sample_bilinear(m, sky) - 3.25).abs().max()) < 1e-12
+
+
+def test_getindex_on_a_map_beyond_2GiB(pj, dev):
+    """Enmap.getindex (copy semantics, negative and non-unit steps) on a 7.5 GB map: checked element-wise
+    against arithmetic on the known content m[j, i] = j * nx + i (exact in Float64)."""
+    shape, wcs = pj.fullsky_geometry(2 * math.pi / 43200)
+    nx, ny = shape
+    data = (torch.arange(ny, dtype=torch.float64, device=dev).mul_(nx).reshape(ny, 1)
+            + torch.arange(nx, dtype=torch.float64, device=dev).reshape(1, nx))
+    m = pj.Enmap(data, wcs)
+    g = m.getindex((40000, -7, 3), (21000, -3, 12))            # both axes backwards with steps
+    xs = torch.arange(40000, 2, -7, dtype=torch.float64, device=dev)          # 1-based columns
+    ys = torch.arange(21000, 11, -3, dtype=torch.float64, device=dev)
+    assert g.shape == (xs.numel(), ys.numel())
+    expect = (ys.reshape(-1, 1) - 1) * nx + (xs.reshape(1, -1) - 1)
+    assert torch.equal(g.data, expect)
+    big = m.getindex((2, 43199), (21601, -1, 1))                               # 7.5 GB result, DEC reversed
+    assert big.shape == (43198, 21601)
+    assert float(big.data[0, 0]) == (ny - 1) * nx + 1 and float(big.data[-1, -1]) == nx - 2
+    assert float(big.data[12345, 23456]) == (ny - 1 - 12345) * nx + 23457
+    s_expect = float(data[:, 1:-1].sum())
+    assert abs(float(big.data.sum()) - s_expect) <= 1e-9 * abs(s_expect)
