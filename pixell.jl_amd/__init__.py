@@ -10,8 +10,8 @@ from . import _lib
 from ._lib import PixellHipError, LIB_PATH
 from .wcs import (AbstractCARWCS, CarClenshawCurtis, CarFejer1, Gnomonic, SkyBoundingBox, getcdelt, getcrpix,
                   getcrval, getunit, is_periodic, jl_mod, rewind, sliced_wcs)
-from .geometry import (JlRange, create_car_wcs, fullsky_geometry, geometry, pad_geometry, skyarea,
-                       slice_geometry)
+from .geometry import (JlRange, create_car_wcs, extent_cyl, fullsky_geometry, geometry, laxes_cyl, pad_geometry,
+                       skyarea, slice_geometry)
 from .enmap import Enmap, NoWCS, getwcs
 from .ops import (ReprojectPlan, fill_random_, fill_sphere_points_, pix2sky, pix2sky_, pix2sky_rewind,
                   pixareamap, pixareamap_, posmap, reproject, rewind_, sample_bilinear, sky2pix, sky2pix_,

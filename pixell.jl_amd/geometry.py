@@ -134,3 +134,31 @@ def skyarea(shape, wcs):
     d1, d2 = min(e0, e1), max(e0, e1)
     d1, d2 = max(-PI / 2, d1), min(PI / 2, d2)
     return (math.sin(d2) - math.sin(d1)) * abs(da) * shape[0]
+
+
+def extent_cyl(shape, wcs, signed=False):
+    """extent_cyl, arbitrary_wcs.jl:134-148: (RA extent at the mean cos(dec), DEC extent) in radians."""
+    n_a, n_d = shape[0], shape[1]
+    d0, dd = wcs.crval[1] * wcs.unit, wcs.cdelt[1] * wcs.unit
+    da = wcs.cdelt[0] * wcs.unit
+    e0 = d0 + (0.5 - wcs.crpix[1]) * dd
+    e1 = d0 + ((n_d + 0.5) - wcs.crpix[1]) * dd
+    d1, d2 = min(e0, e1), max(e0, e1)
+    d1, d2 = max(-PI / 2, d1), min(PI / 2, d2)
+    dsign = 1 if d1 <= d2 else -1
+    mean_cos = (math.sin(d2) - math.sin(d1)) / (d2 - d1)
+    ext = (n_a * da * mean_cos, (d2 - d1) * dsign)
+    return ext if signed else (abs(ext[0]), abs(ext[1]))
+
+
+def _fftfreq(n, fs):
+    """AbstractFFTs.fftfreq(n, fs): [0, 1, ..., ceil(n/2)-1, -floor(n/2), ..., -1] * fs / n."""
+    half = (n + 1) // 2
+    return [k * fs / n for k in range(half)] + [(k - n) * fs / n for k in range(half, n)]
+
+
+def laxes_cyl(shape, wcs):
+    """laxes_cyl, arbitrary_wcs.jl:157-162: multipole axes (l_ra, l_dec) of a cylindrical patch."""
+    ext = extent_cyl(shape[:2], wcs, signed=True)
+    da_bar, dd_bar = ext[0] / shape[0], ext[1] / shape[1]
+    return _fftfreq(shape[0], TWOPI / da_bar), _fftfreq(shape[1], TWOPI / dd_bar)

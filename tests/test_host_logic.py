@@ -216,3 +216,17 @@ def test_enmap_broadcasting_and_pad(pj):
     assert torch.equal(p.view((4, shape[0] + 3), (6, shape[1] + 5)).data, A[0])         # pad round trip
     q = m2.pad(2, 2, mode="corner")
     assert q.shape == (shape[0] + 2, shape[1] + 2) and q.wcs == w and torch.equal(q.data[:shape[1], :shape[0]], A[0])
+
+
+def test_extent_and_laxes_cyl_literals(pj):
+    """test_geometry.jl:318-341"""
+    shape = (3612, 1605)
+    wcs = pj.create_car_wcs(pj.CarClenshawCurtis, (-0.00833333333333, 0.00833333333333), (1806.0, 1358.0),
+                            (33.9416666667, 0.0))
+    assert isapprox(pj.extent_cyl(shape, wcs), [0.5224453478223857, 0.23343778745414823])
+    la, ld = pj.laxes_cyl(shape, wcs)
+    for k, v in ((0, -0.0), (720, -8659.074944442375), (1440, -17318.14988888475), (2160, 17462.467804625456),
+                 (2880, 8803.392860183081), (3600, 144.31791574070627)):
+        assert abs(la[k] - v) <= 1.5e-8 * max(abs(v), 1e-300) + (1e-12 if v == 0 else 0)
+    for k, v in ((0, 0.0), (400, 10766.355140191221), (1200, -10900.934579443612), (1600, -134.57943925239027)):
+        assert abs(ld[k] - v) <= 1.5e-8 * max(abs(v), 1e-300) + (1e-12 if v == 0 else 0)
