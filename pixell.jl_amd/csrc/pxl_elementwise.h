@@ -1,0 +1,73 @@
+// pxl_elementwise.h -- streaming evaluators: pix2sky / sky2pix on 2xN and SoA batches; included by pxl_kernels.hip (one translation unit, -ffp-contract=off).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// elementwise evaluators (A9-A13): one (c1, c2) pair = 16 B in, 16 B out per lane
+// ------------------------------------------------------------------------------------------------
+// Each lane handles UNR points per trip, all loads issued before the arithmetic so several 16-B requests
+// per lane are in flight (a single dependent load/store per trip left the stream at 57 % of HBM peak).
+#define PXL_UNR 4
+__global__ __launch_bounds__(256) void k_pix2sky_pairs(CarAffine c, int64_t n, const double2* pix,
+                                                       double2* sky, int mode) {
+    // mode 0: affine only; 1: rewind; 2: rewind and leave m = rewound - ref for the unwrap passes (ref = 0)
+    // a block sweeps contiguous chunks of 256*UNR points (like a copy kernel): the UNR requests of a lane
+    // are 4 KiB apart, not a power-of-two number of MiB apart (which camps on one HBM channel)
+    const int64_t chunk = (int64_t)blockDim.x * PXL_UNR;
+    for (int64_t k0 = (int64_t)blockIdx.x * chunk + threadIdx.x; k0 < n; k0 += (int64_t)gridDim.x * chunk) {
+        double2 p[PXL_UNR];
+#pragma unroll
+        for (int u = 0; u < PXL_UNR; ++u) {
+            int64_t k = k0 + u * blockDim.x;
+            p[u] = (k < n) ? pix[k] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < PXL_UNR; ++u) {
+            int64_t k = k0 + u * blockDim.x;
+            double a = p2s_ra(c, p[u].x);
+            double d = p2s_dec(c, p[u].y);
+            if (mode) { a = rewind(a, PXL_TWOPI_D, 0.0); d = rewind(d, PXL_TWOPI_D, 0.0); }
+            if (mode == 2) { a = a - 0.0; d = d - 0.0; }        // angles .-= ref_angle  (enmap_ops.jl:28)
+            if (k < n) sky[k] = make_double2(a, d);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pix2sky_soa(CarAffine c, int64_t n, const double* __restrict__ ip,
+                                                     const double* __restrict__ jp, double* __restrict__ ra,
+                                                     double* __restrict__ dec, int safe) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        double a = p2s_ra(c, ip[k]);
+        double d = p2s_dec(c, jp[k]);
+        if (safe) { a = rewind(a, PXL_TWOPI_D, 0.0); d = rewind(d, PXL_TWOPI_D, 0.0); }
+        ra[k] = a; dec[k] = d;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sky2pix_pairs(Sky2Pix s, int64_t n, const double2* sky,
+                                                       double2* pix) {
+    const int64_t chunk = (int64_t)blockDim.x * PXL_UNR;
+    for (int64_t k0 = (int64_t)blockIdx.x * chunk + threadIdx.x; k0 < n; k0 += (int64_t)gridDim.x * chunk) {
+        double2 v[PXL_UNR];
+#pragma unroll
+        for (int u = 0; u < PXL_UNR; ++u) {
+            int64_t k = k0 + u * blockDim.x;
+            v[u] = (k < n) ? sky[k] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < PXL_UNR; ++u) {
+            int64_t k = k0 + u * blockDim.x;
+            if (k < n) pix[k] = make_double2(s2p_x(s, v[u].x), s2p_y(s, v[u].y));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sky2pix_soa(Sky2Pix s, int64_t n, const double* __restrict__ ra,
+                                                     const double* __restrict__ dec, double* __restrict__ ip,
+                                                     double* __restrict__ jp) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        ip[k] = s2p_x(s, ra[k]);
+        jp[k] = s2p_y(s, dec[k]);
+    }
+}

@@ -4,7 +4,15 @@
 // no MFMA.  The design rules are the memory ones: 16 B per lane coalesced loads/stores, source rows
 // staged through LDS once per output tile, XCD-aware tile order so neighbouring tiles share an L2.
 //
-// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared   (see build.py)
+// One translation unit; the kernels live in topical headers included below:
+//   pxl_device.h         shared device arithmetic (Julia mod, rewind, CAR affine, sky2pix roundings, taps)
+//   pxl_elementwise.h    pix2sky / sky2pix streams            pxl_unwrap.h     unwind! scan, rewind!
+//   pxl_maps.h           posmap, pixareamap                   pxl_tan.h        Gnomonic evaluators
+//   pxl_reproject.h      tables, gather + register-staged     pxl_reproject_dma.h  the LDS-DMA kernel (fast path)
+//   pxl_sample.h         CAR<->TAN reprojection, sampler      pxl_misc.h       FITS staging, synthetic data
+// This file keeps the error plumbing and the extern "C" entry points.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared   (csrc/Makefile)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -61,834 +69,14 @@ static inline unsigned stream_grid(int64_t work_items, int block) {
     return (unsigned)nb;
 }
 
-// ------------------------------------------------------------------------------------------------
-// elementwise evaluators (A9-A13): one (c1, c2) pair = 16 B in, 16 B out per lane
-// ------------------------------------------------------------------------------------------------
-// Each lane handles UNR points per trip, all loads issued before the arithmetic so several 16-B requests
-// per lane are in flight (a single dependent load/store per trip left the stream at 57 % of HBM peak).
-#define PXL_UNR 4
-__global__ __launch_bounds__(256) void k_pix2sky_pairs(CarAffine c, int64_t n, const double2* pix,
-                                                       double2* sky, int mode) {
-    // mode 0: affine only; 1: rewind; 2: rewind and leave m = rewound - ref for the unwrap passes (ref = 0)
-    // a block sweeps contiguous chunks of 256*UNR points (like a copy kernel): the UNR requests of a lane
-    // are 4 KiB apart, not a power-of-two number of MiB apart (which camps on one HBM channel)
-    const int64_t chunk = (int64_t)blockDim.x * PXL_UNR;
-    for (int64_t k0 = (int64_t)blockIdx.x * chunk + threadIdx.x; k0 < n; k0 += (int64_t)gridDim.x * chunk) {
-        double2 p[PXL_UNR];
-#pragma unroll
-        for (int u = 0; u < PXL_UNR; ++u) {
-            int64_t k = k0 + u * blockDim.x;
-            p[u] = (k < n) ? pix[k] : make_double2(0.0, 0.0);
-        }
-#pragma unroll
-        for (int u = 0; u < PXL_UNR; ++u) {
-            int64_t k = k0 + u * blockDim.x;
-            double a = p2s_ra(c, p[u].x);
-            double d = p2s_dec(c, p[u].y);
-            if (mode) { a = rewind(a, PXL_TWOPI_D, 0.0); d = rewind(d, PXL_TWOPI_D, 0.0); }
-            if (mode == 2) { a = a - 0.0; d = d - 0.0; }        // angles .-= ref_angle  (enmap_ops.jl:28)
-            if (k < n) sky[k] = make_double2(a, d);
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_pix2sky_soa(CarAffine c, int64_t n, const double* __restrict__ ip,
-                                                     const double* __restrict__ jp, double* __restrict__ ra,
-                                                     double* __restrict__ dec, int safe) {
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-        double a = p2s_ra(c, ip[k]);
-        double d = p2s_dec(c, jp[k]);
-        if (safe) { a = rewind(a, PXL_TWOPI_D, 0.0); d = rewind(d, PXL_TWOPI_D, 0.0); }
-        ra[k] = a; dec[k] = d;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_sky2pix_pairs(Sky2Pix s, int64_t n, const double2* sky,
-                                                       double2* pix) {
-    const int64_t chunk = (int64_t)blockDim.x * PXL_UNR;
-    for (int64_t k0 = (int64_t)blockIdx.x * chunk + threadIdx.x; k0 < n; k0 += (int64_t)gridDim.x * chunk) {
-        double2 v[PXL_UNR];
-#pragma unroll
-        for (int u = 0; u < PXL_UNR; ++u) {
-            int64_t k = k0 + u * blockDim.x;
-            v[u] = (k < n) ? sky[k] : make_double2(0.0, 0.0);
-        }
-#pragma unroll
-        for (int u = 0; u < PXL_UNR; ++u) {
-            int64_t k = k0 + u * blockDim.x;
-            if (k < n) pix[k] = make_double2(s2p_x(s, v[u].x), s2p_y(s, v[u].y));
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_sky2pix_soa(Sky2Pix s, int64_t n, const double* __restrict__ ra,
-                                                     const double* __restrict__ dec, double* __restrict__ ip,
-                                                     double* __restrict__ jp) {
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-        ip[k] = s2p_x(s, ra[k]);
-        jp[k] = s2p_y(s, dec[k]);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// unwind! (A8, car_proj.jl:110-112 -> enmap_ops.jl:26-32): rewind, subtract ref, DSP.unwrap along the
-// point axis, add ref.  With m[k] the rewound value,
-//     y[0] = m[0];   y[k] = m[k] - r_k * P,   r_k = rint((m[k] - y[k-1]) / P)        (DSP.jl unwrap kernel)
-// y[k-1] is itself m[k-1] - r_{k-1} * P, so the only state the recurrence carries is the INTEGER r_{k-1}:
-//     r_k = F_k(r_{k-1}),   F_k(r) = rint((m[k] - (m[k-1] - r*P)) / P)  =  r + c_k   with c_k in {-1,0,1},
-// where c_k can depend on r only when (m[k]-m[k-1])/P sits within rounding of a tie.  That makes the scan
-// parallel AND exact:
-//   1. c_k := rint((m[k] - m[k-1]) / P)                                  (nominal increments, int8)
-//   2. r := inclusive prefix sum of c                                    (two-level block scan, int32)
-//   3. verify every k with the reference's own floating-point formula: t = rint((m[k] - (m[k-1] - r[k-1]*P))/P);
-//      where t != r[k], fix c_k += t - r[k] and raise a flag
-//   4. if anything was fixed, repeat 2-3 once (device-gated); a clean verification means r is -- by induction from r_0 = 0 -- exactly
-//      the sequential result, and y[k] = m[k] - r[k]*P + ref is written.  Otherwise (adversarial ties) the
-//      exact serial kernel below runs instead.  Nothing synchronises with the host.
-// PARITY UNPINNED (DSP.jl is not in the reference tree); the oracle's pxl_unwind_row_cpu is the definition.
-// ------------------------------------------------------------------------------------------------
-#define PXL_SCAN_ITEMS 16
-#define PXL_SCAN_BLOCK (256 * PXL_SCAN_ITEMS)
-
-__global__ __launch_bounds__(256) void k_unwrap_incr(int64_t n, int nrow, const double* __restrict__ m2, double period,
-                                                     int8_t* __restrict__ c) {
-    // m2: nrow x N interleaved rewound values (nrow = 2 for coordinate batches, 1 for a plain vector); c: [nrow][n]
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-        for (int row = 0; row < nrow; ++row) {
-            int v = 0;
-            if (k > 0) v = (int)rint((m2[nrow * k + row] - m2[nrow * (k - 1) + row]) / period);
-            c[row * n + k] = (int8_t)v;
-        }
-    }
-}
-
-// local inclusive scan of 4096-element blocks; blockIdx.y = coordinate row
-template <typename TIN>
-__global__ __launch_bounds__(256) void k_scan_local(int64_t n, const TIN* __restrict__ c, int32_t* __restrict__ rloc,
-                                                    int32_t* __restrict__ bsum, int64_t nb, const int32_t* __restrict__ gate) {
-    __shared__ int32_t wsum[4];
-    if (gate && *gate == 0) return;         // second pass: only if the first verification found mismatches
-    const int row = blockIdx.y;
-    const int64_t base = (int64_t)blockIdx.x * PXL_SCAN_BLOCK + (int64_t)threadIdx.x * PXL_SCAN_ITEMS;
-    int32_t v[PXL_SCAN_ITEMS];
-    int32_t run = 0;
-#pragma unroll
-    for (int i = 0; i < PXL_SCAN_ITEMS; ++i) {
-        int64_t k = base + i;
-        run += (k < n) ? (int32_t)c[row * n + k] : 0;
-        v[i] = run;
-    }
-    // exclusive scan of the per-thread totals across the block: wave shuffle scan + 4 wave totals in LDS
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int32_t incl = run;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int32_t o = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += o;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int32_t woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wsum[w];
-    const int32_t excl = woff + incl - run;
-#pragma unroll
-    for (int i = 0; i < PXL_SCAN_ITEMS; ++i) {
-        int64_t k = base + i;
-        if (k < n) rloc[row * n + k] = v[i] + excl;
-    }
-    if (threadIdx.x == 255) bsum[row * nb + blockIdx.x] = woff + incl;
-}
-
-// exclusive scan of the block totals (one block per coordinate row walks them with a running carry)
-__global__ __launch_bounds__(1024) void k_scan_bsums(int64_t nb, const int32_t* __restrict__ bsum, int32_t* __restrict__ boff,
-                                                     const int32_t* __restrict__ gate) {
-    __shared__ int32_t wsum[16];
-    __shared__ int32_t carry_s;
-    if (gate && *gate == 0) return;
-    const int row = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int64_t b0 = 0; b0 < nb; b0 += 1024) {
-        int64_t b = b0 + threadIdx.x;
-        int32_t x = (b < nb) ? bsum[row * nb + b] : 0;
-        int32_t incl = x;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            int32_t o = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += o;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        int32_t woff = 0;
-        for (int w = 0; w < wave; ++w) woff += wsum[w];
-        const int32_t carry = carry_s;
-        if (b < nb) boff[row * nb + b] = carry + woff + incl - x;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + incl;
-        __syncthreads();
-    }
-}
-
-__device__ inline int32_t scan_value(const int32_t* rloc, const int32_t* boff, int64_t n, int64_t nb, int row, int64_t k) {
-    return rloc[row * n + k] + boff[row * nb + k / PXL_SCAN_BLOCK];
-}
-
-__global__ __launch_bounds__(256) void k_unwrap_verify(int64_t n, int nrow, const double* __restrict__ m2, double period,
-                                                       int8_t* __restrict__ c, const int32_t* __restrict__ rloc,
-                                                       const int32_t* __restrict__ boff, int64_t nb,
-                                                       int32_t* __restrict__ flag, const int32_t* __restrict__ gate) {
-    if (gate && *gate == 0) return;
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    bool bad = false;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; k < n; k += stride) {
-        for (int row = 0; row < nrow; ++row) {
-            const int32_t rprev = scan_value(rloc, boff, n, nb, row, k - 1);
-            const int32_t rk = scan_value(rloc, boff, n, nb, row, k);
-            const double yprev = m2[nrow * (k - 1) + row] - (double)rprev * period;  // y[k-1] as the reference forms it
-            const double q = (m2[nrow * k + row] - yprev) / period;
-            if (!isfinite(q)) { bad = true; continue; }       // NaN/Inf poison everything after them: serial path
-            const int32_t t = (int32_t)rint(q);
-            if (t != rk) {
-                c[row * n + k] = (int8_t)((int)c[row * n + k] + (t - rk));
-                bad = true;
-            }
-        }
-    }
-    if (bad) atomicOr(flag, 1);
-}
-
-__global__ __launch_bounds__(256) void k_unwrap_apply(int64_t n, int nrow, double* __restrict__ m2, double period, double ref,
-                                                      const int32_t* __restrict__ rloc, const int32_t* __restrict__ boff,
-                                                      int64_t nb, const int32_t* __restrict__ flag) {
-    // flag[0]: pass 1 found mismatches; flag[1]: pass 2 (run only then) still found some
-    if (flag[0] && flag[1]) return;         // unverified: the serial kernel produces the answer
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-        if (nrow == 2) {
-            double2 m = *reinterpret_cast<const double2*>(m2 + 2 * k);
-            double y0 = m.x, y1 = m.y;
-            if (k > 0) {
-                y0 = m.x - (double)scan_value(rloc, boff, n, nb, 0, k) * period;
-                y1 = m.y - (double)scan_value(rloc, boff, n, nb, 1, k) * period;
-            }
-            *reinterpret_cast<double2*>(m2 + 2 * k) = make_double2(y0 + ref, y1 + ref);
-        } else {
-            double y = m2[k];
-            if (k > 0) y = y - (double)scan_value(rloc, boff, n, nb, 0, k) * period;
-            m2[k] = y + ref;
-        }
-    }
-}
-
-// Exact serial form (one wave per coordinate row, 64 dependent steps per 64 points): the fallback when the
-// speculative scan cannot be verified, and the whole algorithm for tiny batches.  `prewound` = input already
-// holds m = rewind(.) - ref.  gate: run only if *gate != 0 (NULL = always).
-__global__ __launch_bounds__(64) void k_unwind_rows(int64_t n, int nrow, double* __restrict__ sky, double period, double ref,
-                                                    int prewound, const int32_t* __restrict__ gate) {
-    if (gate && !(gate[0] && gate[1])) return;
-    const int row = blockIdx.x;
-    const int lane = threadIdx.x;
-    double prev = 0.0;
-    bool have_prev = false;
-    for (int64_t base = 0; base < n; base += 64) {
-        int64_t k = base + lane;
-        double m = 0.0;
-        if (k < n) m = prewound ? sky[nrow * k + row] : rewind(sky[nrow * k + row], period, ref) - ref;
-        double y = m;
-        int cnt = (int)((n - base) < 64 ? (n - base) : 64);
-        for (int l = 0; l < cnt; ++l) {
-            double ml = __shfl(m, l, 64);
-            double yl = have_prev ? ml - rint((ml - prev) / period) * period : ml;
-            prev = yl;
-            have_prev = true;
-            if (lane == l) y = yl;
-        }
-        if (k < n) sky[nrow * k + row] = y + ref;
-    }
-}
-
-// rewind! on a flat array (enmap_ops.jl:15-19); sub_ref: also subtract ref (first half of unwind!)
-__global__ __launch_bounds__(256) void k_rewind(int64_t n, double* a, double period, double ref, int sub_ref) {
-    const int64_t chunk = (int64_t)blockDim.x * 4;
-    for (int64_t k0 = (int64_t)blockIdx.x * chunk + threadIdx.x; k0 < n; k0 += (int64_t)gridDim.x * chunk) {
-        double v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { int64_t k = k0 + u * blockDim.x; v[u] = (k < n) ? a[k] : 0.0; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            int64_t k = k0 + u * blockDim.x;
-            double r = rewind(v[u], period, ref);
-            if (sub_ref) r = r - ref;
-            if (k < n) a[k] = r;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// posmap (A15) / pixareamap (N4): write-only maps.  Lane = 2 adjacent RA pixels (16 B stores).
-// ------------------------------------------------------------------------------------------------
-// Block = (512-column chunk, chunk of rows): RA (rewound) is computed once per lane and reused for every
-// row of the chunk; DEC / the row area is one evaluation per row.
-#define PXL_POS_ROWS 32
-__global__ __launch_bounds__(256) void k_posmap_car(CarAffine c, int64_t nx, int64_t row0, int64_t nrows,
-                                                    double* __restrict__ ra, double* __restrict__ dec, int safe) {
-    const bool vec = ((nx & 1) == 0) && ((((uintptr_t)ra | (uintptr_t)dec) & 15) == 0);
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;        // 0-based column of the pair
-    if (i >= nx) return;
-    double a0 = p2s_ra(c, (double)(i + 1));
-    double a1 = p2s_ra(c, (double)(i + 2));
-    if (safe) { a0 = rewind(a0, PXL_TWOPI_D, 0.0); a1 = rewind(a1, PXL_TWOPI_D, 0.0); }
-    const int64_t jr0 = (int64_t)blockIdx.y * PXL_POS_ROWS;
-    const int64_t jr1 = (jr0 + PXL_POS_ROWS < nrows) ? jr0 + PXL_POS_ROWS : nrows;
-    for (int64_t jr = jr0; jr < jr1; ++jr) {
-        double d = p2s_dec(c, (double)(row0 + jr + 1));
-        if (safe) d = rewind(d, PXL_TWOPI_D, 0.0);
-        int64_t o = jr * nx + i;
-        if (vec) {
-            *reinterpret_cast<double2*>(ra + o) = make_double2(a0, a1);
-            *reinterpret_cast<double2*>(dec + o) = make_double2(d, d);
-        } else {
-            ra[o] = a0; dec[o] = d;
-            if (i + 1 < nx) { ra[o + 1] = a1; dec[o + 1] = d; }
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_pixareamap_car(CarAffine c, int64_t nx, int64_t row0, int64_t nrows,
-                                                        double* __restrict__ area) {
-    const bool vec = ((nx & 1) == 0) && (((uintptr_t)area & 15) == 0);
-    const double da = fabs(c.da);
-    // one row per blockIdx.y; the row value is computed once per lane and streamed along RA
-    const int64_t jr = blockIdx.y;
-    const double row = (double)(row0 + jr + 1);
-    // enmap_ops.jl:131-134: dec of the two pixel edges, sorted, clamped to the poles
-    double e0 = p2s_dec(c, row - 0.5), e1 = p2s_dec(c, row + 0.5);
-    double d1 = fmin(e0, e1), d2 = fmax(e0, e1);
-    d1 = fmax(-PXL_PI_D / 2, d1); d2 = fmin(PXL_PI_D / 2, d2);
-    const double v = (sin(d2) - sin(d1)) * da;
-    const int64_t npair = (nx + 1) / 2;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < npair; t += (int64_t)gridDim.x * blockDim.x) {
-        int64_t i = t * 2;
-        int64_t o = jr * nx + i;
-        if (vec) *reinterpret_cast<double2*>(area + o) = make_double2(v, v);
-        else { area[o] = v; if (i + 1 < nx) area[o + 1] = v; }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Gnomonic (A16), tan_proj.jl:44-75
-// ------------------------------------------------------------------------------------------------
-struct TanParams { double scale, unit, a0, d0, sd0, cd0, cpx, cpy; };
-static TanParams tan_setup(const pxl_car_wcs& w) {
-    TanParams t;
-    t.scale = 1.0 / w.cdelt[0];
-    t.unit = w.unit;
-    t.a0 = w.crval[0] * (PXL_PI_D / 180);   // deg2rad.(wcs.crval), tan_proj.jl:47
-    t.d0 = w.crval[1] * (PXL_PI_D / 180);
-    t.sd0 = sin(t.d0); t.cd0 = cos(t.d0);
-    t.cpx = w.crpix[0]; t.cpy = w.crpix[1];
-    return t;
-}
-__device__ inline void tan_sky2pix(const TanParams& t, double a, double d, double* x, double* y) {
-    double A = cos(d) * cos(a - t.a0);
-    double F = t.scale / t.unit / (t.sd0 * sin(d) + A * t.cd0);
-    double LINE = -F * (t.cd0 * sin(d) - A * t.sd0);
-    double SAMPLE = -F * cos(d) * sin(a - t.a0);
-    *x = t.cpx - SAMPLE;
-    *y = t.cpy - LINE;
-}
-__device__ inline void tan_pix2sky(const TanParams& t, double i, double j, double* a, double* d) {
-    double X = (t.cpx - i) * t.unit / t.scale;
-    double Y = (t.cpy - j) * t.unit / t.scale;
-    double D = atan(sqrt(X * X + Y * Y));
-    double B = atan2(-X, Y);
-    double sD = sin(D), cD = cos(D), cB = cos(B);
-    double XX = t.sd0 * sD * cB + t.cd0 * cD;
-    double YY = sD * sin(B);
-    *a = t.a0 + atan2(YY, XX);
-    *d = asin(t.sd0 * cD - t.cd0 * sD * cB);
-}
-__global__ __launch_bounds__(256) void k_sky2pix_tan(TanParams t, int64_t n, const double* __restrict__ ra,
-                                                     const double* __restrict__ dec, double* __restrict__ x,
-                                                     double* __restrict__ y) {
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride)
-        tan_sky2pix(t, ra[k], dec[k], &x[k], &y[k]);
-}
-__global__ __launch_bounds__(256) void k_pix2sky_tan(TanParams t, int64_t n, const double* __restrict__ ip,
-                                                     const double* __restrict__ jp, double* __restrict__ ra,
-                                                     double* __restrict__ dec) {
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride)
-        tan_pix2sky(t, ip[k], jp[k], &ra[k], &dec[k]);
-}
-__global__ __launch_bounds__(256) void k_posmap_tan(TanParams t, int64_t nx, int64_t row0, int64_t nrows,
-                                                    double* __restrict__ ra, double* __restrict__ dec) {
-    const int64_t total = nx * nrows;
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += stride) {
-        int64_t jr = k / nx, i = k - jr * nx;
-        tan_pix2sky(t, (double)(i + 1), (double)(row0 + jr + 1), &ra[k], &dec[k]);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Reprojection (R1).
-// ------------------------------------------------------------------------------------------------
-// Separable tables: for output column i (0-based ic) the source cell xi0[ic] (1-based int) and fraction
-// xfx[ic]; same for rows.  (a, d) = pix2sky(out; safe=false) [car_proj.jl:146-147];
-// (x, y) = sky2pix(in; safe=true), division form [car_proj.jl:225-231].
-__global__ __launch_bounds__(256) void k_build_tables(CarAffine out, Sky2Pix in, int64_t nxo, int64_t nyo,
-                                                      int32_t* __restrict__ xi0, double* __restrict__ xfx,
-                                                      int32_t* __restrict__ yj0, double* __restrict__ yfy) {
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nxo + nyo; k += stride) {
-        if (k < nxo) {
-            double a = p2s_ra(out, (double)(k + 1));
-            split_cell(s2p_x(in, a), &xi0[k], &xfx[k]);
-        } else {
-            int64_t j = k - nxo;
-            double d = p2s_dec(out, (double)(j + 1));
-            split_cell(s2p_y(in, d), &yj0[j], &yfy[j]);
-        }
-    }
-}
-
-struct ReprojParams {
-    const double* src;     // (nx, src_nrows, nc)
-    double* dst;           // (nxo, dst_nrows, nc)
-    const int32_t* xi0; const double* xfx;   // nxo entries
-    const int32_t* yj0; const double* yfy;   // nyo entries (absolute output row)
-    int64_t nx, ny, src_row0, src_nrows;
-    int64_t nxo, dst_row0, dst_nrows;
-    int64_t r0, nr;        // output rows handled by this launch, relative to the dst window
-    int32_t nc, periodic;
-    // staged kernel only
-    int32_t rh;            // output rows per tile
-    int32_t seg;           // LDS slot length in doubles (even)
-    int32_t dxpos;         // source column increases with output column
-    int32_t dypos;         // source row increases with output row
-    int32_t ntx, nty;      // tiles along RA / DEC
-    int64_t ntiles, tiles_per_xcd;
-    int32_t flags;         // tuning/diagnostics: 1 = skip source loads, 2 = skip stores, 4 = no XCD remap
-    // LDS-DMA kernel only
-    int32_t ns, pf;        // ring slots (power of two), prefetch distance in output rows
-    const double* zero_page;   // 16 bytes of zeros in device memory
-};
-
-// ---- generic direct-gather kernel: one lane per output pixel pair, 4 taps from global memory each.
-//      Used when a tile's source footprint does not fit the LDS ring (large down-scaling) and as the
-//      cross-check variant.
-__global__ __launch_bounds__(256) void k_reproject_gather(ReprojParams p) {
-    const int64_t npair = (p.nxo + 1) / 2;
-    const int64_t total = npair * p.nr;
-    const int c = blockIdx.y;
-    SrcView m{p.src + (int64_t)c * p.nx * p.src_nrows, p.nx, p.ny, p.src_row0, p.src_nrows, p.periodic};
-    double* dplane = p.dst + (int64_t)c * p.nxo * p.dst_nrows;
-    const bool vec = ((p.nxo & 1) == 0) && (((uintptr_t)p.dst & 15) == 0);
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        int64_t rr = t / npair;
-        int64_t i = (t - rr * npair) * 2;
-        int64_t r = p.r0 + rr;
-        int64_t j0 = p.yj0[p.dst_row0 + r];
-        double fy = p.yfy[p.dst_row0 + r];
-        double v0 = bilerp_cells(m, p.xi0[i], p.xfx[i], j0, fy);
-        int64_t o = r * p.nxo + i;
-        if (i + 1 < p.nxo) {
-            double v1 = bilerp_cells(m, p.xi0[i + 1], p.xfx[i + 1], j0, fy);
-            if (vec) *reinterpret_cast<double2*>(dplane + o) = make_double2(v0, v1);
-            else { dplane[o] = v0; dplane[o + 1] = v1; }
-        } else {
-            dplane[o] = v0;
-        }
-    }
-}
-
-// ---- staged kernel: ONE WAVEFRONT PER OUTPUT TILE.
-//
-// A tile is TW = 128*PAIRS output columns x rh output rows of one component plane.  The wave marches
-// down the tile's rows.  The two source rows an output row needs (j0, j0+1) live in a 4-slot LDS ring
-// (slot = row & 3, tagged with the row id), each slot holding the contiguous source-column segment the
-// tile's columns touch, loaded with 16 B/lane coalesced reads; the RA seam of a full-sky map is
-// resolved while staging (segment column u -> u mod nx), so the interpolation itself never sees it.
-// Rows for output row r+1 are prefetched into registers while row r is computed and stored.
-// Output is written with 16 B/lane coalesced stores (lane = 2 adjacent RA pixels per PAIR).
-//
-// Tiles whose columns do not fit the slot (the rewind discontinuity of a partial-sky source falling
-// inside the tile) fall back, wave-uniformly, to direct taps.
-#define PXL_NS 4
-#define PXL_MAXCH 5     // 16-B chunks of 64 lanes per slot: slot <= 5*128 doubles
-
-template <bool VEC>
-__device__ inline void load_row_regs(const ReprojParams& p, const double* plane, int64_t j, int64_t cbase0,
-                                     int lane, double2 (&regs)[PXL_MAXCH]) {
-    // j: 1-based absolute source row (any integer).  Rows outside the map / resident window read as 0.
-    int64_t jr = j - 1 - p.src_row0;
-    const bool row_ok = (j >= 1) && (j <= p.ny) && (jr >= 0) && (jr < p.src_nrows) && !(p.flags & 1);
-    const double* rowp = plane + (row_ok ? jr : 0) * p.nx;
-#pragma unroll
-    for (int ch = 0; ch < PXL_MAXCH; ++ch) {
-        int k = ch * 128 + 2 * lane;
-        double2 v = make_double2(0.0, 0.0);
-        if (k < p.seg && row_ok) {
-            int64_t u = cbase0 + k;                   // 0-based unwrapped column of the chunk's first element
-            if (VEC) {
-                // nx even and u even: the pair never straddles the seam or the map edge
-                bool ok = true;
-                if (p.periodic) { u %= p.nx; if (u < 0) u += p.nx; }
-                else ok = (u >= 0) && (u < p.nx);
-                if (ok) v = *reinterpret_cast<const double2*>(rowp + u);
-            } else {
-                int64_t u0 = u, u1 = u + 1;
-                bool ok0 = true, ok1 = true;
-                if (p.periodic) {
-                    u0 %= p.nx; if (u0 < 0) u0 += p.nx;
-                    u1 %= p.nx; if (u1 < 0) u1 += p.nx;
-                } else {
-                    ok0 = (u0 >= 0) && (u0 < p.nx);
-                    ok1 = (u1 >= 0) && (u1 < p.nx);
-                }
-                if (ok0) v.x = rowp[u0];
-                if (ok1) v.y = rowp[u1];
-            }
-        }
-        regs[ch] = v;
-    }
-}
-
-__device__ inline void store_row_lds(const ReprojParams& p, double* slot, int lane, const double2 (&regs)[PXL_MAXCH]) {
-#pragma unroll
-    for (int ch = 0; ch < PXL_MAXCH; ++ch) {
-        int k = ch * 128 + 2 * lane;
-        if (k < p.seg) *reinterpret_cast<double2*>(slot + k) = regs[ch];
-    }
-}
-
-template <int PAIRS, bool VEC>
-__global__ __launch_bounds__(64) void k_reproject_staged(ReprojParams p) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];   // PXL_NS * seg doubles
-    const int lane = threadIdx.x;
-    constexpr int TW = 128 * PAIRS;
-
-    // XCD-aware decode: hardware deals blocks round-robin over the 8 XCDs (b % 8); give each XCD a
-    // contiguous run of tiles so RA-neighbouring tiles (which share 128-B lines at their edges and the
-    // same source rows) hit the same L2.  Placement only affects speed, never correctness.
-    const int64_t b = blockIdx.x;
-    const int64_t t = (p.flags & 4) ? b : (b & 7) * p.tiles_per_xcd + (b >> 3);
-    if (t >= p.ntiles) return;
-    const int tx = (int)(t % p.ntx);
-    const int64_t trest = t / p.ntx;
-    const int ty = (int)(trest % p.nty);
-    const int c = (int)(trest / p.nty);
-
-    const double* splane = p.src + (int64_t)c * p.nx * p.src_nrows;
-    double* dplane = p.dst + (int64_t)c * p.nxo * p.dst_nrows;
-
-    const int64_t c0 = (int64_t)tx * TW;                       // first output column of the tile
-    const int64_t clast = (c0 + TW < p.nxo ? c0 + TW : p.nxo) - 1;
-    const int64_t rb = p.r0 + (int64_t)ty * p.rh;              // rows relative to the dst window
-    const int64_t re = (rb + p.rh < p.r0 + p.nr) ? rb + p.rh : p.r0 + p.nr;
-
-    // ---- per-lane column setup
-    const int64_t a = p.dxpos ? p.xi0[c0] : p.xi0[clast];      // 1-based source cell of the tile's low end
-    const int64_t ua = a - 1;
-    const int64_t cbase0 = ua & ~(int64_t)1;                   // even 0-based column at slot index 0
-    int dloc[PAIRS][2];
-    double fx[PAIRS][2];
-    bool act[PAIRS][2];
-    bool fits = true;
-#pragma unroll
-    for (int q = 0; q < PAIRS; ++q) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            int64_t col = c0 + q * 128 + 2 * lane + e;
-            act[q][e] = col < p.nxo;
-            int64_t i0 = act[q][e] ? p.xi0[col] : a;
-            fx[q][e] = act[q][e] ? p.xfx[col] : 0.0;
-            int64_t d = i0 - a;
-            if (p.periodic) { d %= p.nx; if (d < 0) d += p.nx; }
-            d += ua - cbase0;
-            if (d < 0 || d + 1 >= p.seg) fits = false;
-            dloc[q][e] = (int)d;
-        }
-    }
-    const bool vec_store = ((p.nxo & 1) == 0) && (((uintptr_t)p.dst & 15) == 0);
-
-    if (!__all(fits)) {
-        // wave-uniform fallback: direct taps for this tile
-        SrcView m{splane, p.nx, p.ny, p.src_row0, p.src_nrows, p.periodic};
-        for (int64_t r = rb; r < re; ++r) {
-            int64_t j0 = p.yj0[p.dst_row0 + r];
-            double fy = p.yfy[p.dst_row0 + r];
-#pragma unroll
-            for (int q = 0; q < PAIRS; ++q)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    int64_t col = c0 + q * 128 + 2 * lane + e;
-                    if (act[q][e]) dplane[r * p.nxo + col] = bilerp_cells(m, p.xi0[col], fx[q][e], j0, fy);
-                }
-        }
-        return;
-    }
-
-    // ---- ring state (wave-uniform): tag of the source row held by each slot
-    int64_t tag0 = INT64_MIN, tag1 = INT64_MIN, tag2 = INT64_MIN, tag3 = INT64_MIN;
-    auto resident = [&](int64_t j) -> bool {
-        int s = (int)(j & 3);
-        int64_t tg = (s == 0) ? tag0 : (s == 1) ? tag1 : (s == 2) ? tag2 : tag3;
-        return tg == j;
-    };
-    auto settag = [&](int64_t j) {
-        int s = (int)(j & 3);
-        if (s == 0) tag0 = j; else if (s == 1) tag1 = j; else if (s == 2) tag2 = j; else tag3 = j;
-    };
-
-    // per-row table entries of this tile live in lane (r - rb) and are broadcast with v_readlane
-    // (no scalar-memory round trip inside the row loop); rh <= 64
-    int my_j0 = 0;
-    double my_fy = 0.0;
-    if (rb + lane < re) { my_j0 = p.yj0[p.dst_row0 + rb + lane]; my_fy = p.yfy[p.dst_row0 + rb + lane]; }
-    auto row_j0 = [&](int64_t r) -> int64_t { return (int64_t)__builtin_amdgcn_readlane(my_j0, (int)(r - rb)); };
-    auto row_fy = [&](int64_t r) -> double {
-        int lo = __builtin_amdgcn_readlane(__double2loint(my_fy), (int)(r - rb));
-        int hi = __builtin_amdgcn_readlane(__double2hiint(my_fy), (int)(r - rb));
-        return __hiloint2double(hi, lo);
-    };
-
-    double2 ra_[PXL_MAXCH], rb_[PXL_MAXCH];
-    {   // prologue: rows of the first output row
-        int64_t j0 = row_j0(rb);
-        load_row_regs<VEC>(p, splane, j0, cbase0, lane, ra_);
-        load_row_regs<VEC>(p, splane, j0 + 1, cbase0, lane, rb_);
-        store_row_lds(p, lds + (j0 & 3) * p.seg, lane, ra_);
-        store_row_lds(p, lds + ((j0 + 1) & 3) * p.seg, lane, rb_);
-        settag(j0); settag(j0 + 1);
-        __syncthreads();
-    }
-
-    for (int64_t r = rb; r < re; ++r) {
-        const int64_t j0 = row_j0(r);
-        const double fy = row_fy(r);
-
-        // prefetch the rows output row r+1 needs and the ring lacks (global -> registers)
-        bool needA = false, needB = false;
-        int64_t jn = 0;
-        if (r + 1 < re) {
-            jn = row_j0(r + 1);
-            needA = !resident(jn);
-            needB = !resident(jn + 1);
-            if (needA) load_row_regs<VEC>(p, splane, jn, cbase0, lane, ra_);
-            if (needB) load_row_regs<VEC>(p, splane, jn + 1, cbase0, lane, rb_);
-        }
-
-        // interpolate output row r from LDS
-        const double* T = lds + (j0 & 3) * p.seg;
-        const double* B = lds + ((j0 + 1) & 3) * p.seg;
-        const double wy = 1 - fy;
-#pragma unroll
-        for (int q = 0; q < PAIRS; ++q) {
-            double v[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                int d = dloc[q][e];
-                double wx = 1 - fx[q][e];
-                double top = wx * T[d] + fx[q][e] * T[d + 1];
-                double bot = wx * B[d] + fx[q][e] * B[d + 1];
-                v[e] = wy * top + fy * bot;
-            }
-            int64_t col = c0 + q * 128 + 2 * lane;
-            double* o = dplane + r * p.nxo + col;
-            if (p.flags & 2) { if (v[0] == 1.2345e300) o[0] = v[1]; }       // diagnostics: keep v live, never store
-            else if (vec_store) { if (act[q][0]) *reinterpret_cast<double2*>(o) = make_double2(v[0], v[1]); }
-            else { if (act[q][0]) o[0] = v[0]; if (act[q][1]) o[1] = v[1]; }
-        }
-
-        if (needA || needB) {
-            __syncthreads();                       // every lane is done reading the slots being replaced
-            if (needA) { store_row_lds(p, lds + (jn & 3) * p.seg, lane, ra_); settag(jn); }
-            if (needB) { store_row_lds(p, lds + ((jn + 1) & 3) * p.seg, lane, rb_); settag(jn + 1); }
-            __syncthreads();
-        }
-    }
-}
-
-
+#include "pxl_elementwise.h"
+#include "pxl_unwrap.h"
+#include "pxl_maps.h"
+#include "pxl_tan.h"
+#include "pxl_reproject.h"
 #include "pxl_reproject_dma.h"
-
-// ---- generic (non-separable) bilinear reprojection between CAR and Gnomonic maps (N2).
-// Per output pixel: (ra, dec) = pix2sky(out) [car_proj.jl:146-147 safe=false | tan_proj.jl:59-75];
-// (x, y) = sky2pix(in) [car_proj.jl:225-231 safe=true | tan_proj.jl:44-57]; 2x2 direct taps + lerp.
-// A sky point behind a Gnomonic source's tangent plane (cos c <= 0) is not on that map: it reads as 0.
-// FP64-transcendental bound (about ten libm calls per pixel), tolerance-checked rather than bit-exact.
-struct GenericParams {
-    const double* src; double* dst;
-    int64_t nx, ny, nxo, nyo;
-    int32_t nc, periodic, proj_in, proj_out;
-    CarAffine out_car; TanParams out_tan;
-    Sky2Pix in_car; TanParams in_tan;
-};
-__global__ __launch_bounds__(256) void k_reproject_generic(GenericParams p) {
-    const int64_t total = p.nxo * p.nyo;
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        const int64_t jr = t / p.nxo, i = t - jr * p.nxo;
-        double ra, dec;
-        if (p.proj_out == PXL_PROJ_TAN) tan_pix2sky(p.out_tan, (double)(i + 1), (double)(jr + 1), &ra, &dec);
-        else { ra = p2s_ra(p.out_car, (double)(i + 1)); dec = p2s_dec(p.out_car, (double)(jr + 1)); }
-        double x, y;
-        bool visible = true;
-        if (p.proj_in == PXL_PROJ_TAN) {
-            tan_sky2pix(p.in_tan, ra, dec, &x, &y);
-            visible = (p.in_tan.sd0 * sin(dec) + cos(dec) * cos(ra - p.in_tan.a0) * p.in_tan.cd0) > 0.0;
-        } else { x = s2p_x(p.in_car, ra); y = s2p_y(p.in_car, dec); }
-        const bool fin = isfinite(x) && isfinite(y);
-        int32_t i0, j0; double fx, fy;
-        split_cell(x, &i0, &fx);
-        split_cell(y, &j0, &fy);
-        for (int c = 0; c < p.nc; ++c) {
-            SrcView m{p.src + (int64_t)c * p.nx * p.ny, p.nx, p.ny, 0, p.ny, p.periodic};
-            double v = visible ? bilerp_cells(m, i0, fx, j0, fy) : 0.0;
-            p.dst[(int64_t)c * total + t] = fin ? v : __builtin_nan("");
-        }
-    }
-}
-
-// ---- scattered sample: fused sky2pix!(safe=true) [car_proj.jl:165-193] + 2x2 gather + lerp.
-// An irregular gather: each point touches two 16-byte spans in two different rows of a multi-GB map, so
-// the kernel is bound by random-sector fetches, not by bytes.  Each lane handles PXL_SUNR points per trip
-// and issues all their taps before any arithmetic (4x the gathers in flight per lane); tap indices are
-// 32-bit and the RA wrap is one conditional add/subtract (safe sky2pix keeps x within half a period of the
-// map centre), with the oracle's full modulo kept only as the out-of-range path.
-#define PXL_SUNR 4
-__device__ inline int64_t wrap_col(int64_t i, int64_t nx) {          // 1-based column of a periodic map
-    if (i >= 1 - nx && i <= 2 * nx) { if (i > nx) i -= nx; else if (i < 1) i += nx; return i; }
-    i = (i - 1) % nx; if (i < 0) i += nx; return i + 1;
-}
-__global__ __launch_bounds__(256) void k_sample_bilinear(Sky2Pix s, const double* __restrict__ src, int64_t nx,
-                                                         int64_t ny, int32_t nc, int64_t row0, int64_t nrows,
-                                                         int periodic, int64_t n, const double2* __restrict__ sky,
-                                                         double* __restrict__ out) {
-    const int64_t chunk = (int64_t)blockDim.x * PXL_SUNR;
-    const int64_t plane = nx * nrows;
-    for (int64_t k0 = (int64_t)blockIdx.x * chunk + threadIdx.x; k0 < n; k0 += (int64_t)gridDim.x * chunk) {
-        double2 ad[PXL_SUNR];
-#pragma unroll
-        for (int u = 0; u < PXL_SUNR; ++u) {
-            int64_t k = k0 + u * blockDim.x;
-            ad[u] = (k < n) ? sky[k] : make_double2(0.0, 0.0);
-        }
-        int64_t o00[PXL_SUNR], o10[PXL_SUNR], o01[PXL_SUNR], o11[PXL_SUNR];   // element offsets, -1 = reads as 0
-        double fx[PXL_SUNR], fy[PXL_SUNR];
-        bool fin[PXL_SUNR];
-#pragma unroll
-        for (int u = 0; u < PXL_SUNR; ++u) {
-            double x = s2p_x(s, ad[u].x), y = s2p_y(s, ad[u].y);
-            fin[u] = isfinite(x) && isfinite(y);
-            int32_t i0, j0;
-            split_cell(x, &i0, &fx[u]);
-            split_cell(y, &j0, &fy[u]);
-            int64_t ia = i0, ib = (int64_t)i0 + 1;
-            bool oka = true, okb = true;
-            if (periodic) { ia = wrap_col(ia, nx); ib = wrap_col(ib, nx); }
-            else { oka = (ia >= 1 && ia <= nx); okb = (ib >= 1 && ib <= nx); }
-            int64_t ja = (int64_t)j0 - 1 - row0, jb = ja + 1;                    // resident row indices
-            bool rowa = (j0 >= 1 && j0 <= ny && ja >= 0 && ja < nrows);
-            bool rowb = ((int64_t)j0 + 1 >= 1 && (int64_t)j0 + 1 <= ny && jb >= 0 && jb < nrows);
-            o00[u] = (rowa && oka) ? ja * nx + (ia - 1) : -1;
-            o10[u] = (rowa && okb) ? ja * nx + (ib - 1) : -1;
-            o01[u] = (rowb && oka) ? jb * nx + (ia - 1) : -1;
-            o11[u] = (rowb && okb) ? jb * nx + (ib - 1) : -1;
-        }
-        for (int c = 0; c < nc; ++c) {
-            const double* pl = src + (int64_t)c * plane;
-            double m00[PXL_SUNR], m10[PXL_SUNR], m01[PXL_SUNR], m11[PXL_SUNR];
-#pragma unroll
-            for (int u = 0; u < PXL_SUNR; ++u) {
-                m00[u] = o00[u] >= 0 ? pl[o00[u]] : 0.0;
-                m10[u] = o10[u] >= 0 ? pl[o10[u]] : 0.0;
-                m01[u] = o01[u] >= 0 ? pl[o01[u]] : 0.0;
-                m11[u] = o11[u] >= 0 ? pl[o11[u]] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < PXL_SUNR; ++u) {
-                int64_t k = k0 + u * blockDim.x;
-                double top = (1 - fx[u]) * m00[u] + fx[u] * m10[u];
-                double bot = (1 - fx[u]) * m01[u] + fx[u] * m11[u];
-                double v = (1 - fy[u]) * top + fy[u] * bot;
-                if (k < n) out[(int64_t)c * n + k] = fin[u] ? v : __builtin_nan("");
-            }
-        }
-    }
-}
-
-// ---- FITS staging (N3): big-endian image data <-> native Float64, on the device (enmap.jl:198-237 reads and
-// writes BITPIX -64/-32 image HDUs through CFITSIO; here the raw bytes are copied to HBM and swapped there).
-__global__ __launch_bounds__(256) void k_bswap_to_f64(const void* raw, double* dst,
-                                                      int64_t n, int bitpix) {
-    const int64_t chunk = (int64_t)blockDim.x * 4;
-    for (int64_t k0 = (int64_t)blockIdx.x * chunk + threadIdx.x; k0 < n; k0 += (int64_t)gridDim.x * chunk) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            int64_t k = k0 + u * blockDim.x;
-            if (k >= n) continue;
-            if (bitpix == -64) {
-                uint64_t v = __builtin_bswap64(reinterpret_cast<const uint64_t*>(raw)[k]);
-                dst[k] = __longlong_as_double((long long)v);
-            } else {            // -32: IEEE single, widened exactly
-                uint32_t v = __builtin_bswap32(reinterpret_cast<const uint32_t*>(raw)[k]);
-                dst[k] = (double)__uint_as_float(v);
-            }
-        }
-    }
-}
-__global__ __launch_bounds__(256) void k_f64_to_be(const double* __restrict__ src, uint64_t* __restrict__ raw, int64_t n) {
-    const int64_t chunk = (int64_t)blockDim.x * 4;
-    for (int64_t k0 = (int64_t)blockIdx.x * chunk + threadIdx.x; k0 < n; k0 += (int64_t)gridDim.x * chunk) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            int64_t k = k0 + u * blockDim.x;
-            if (k < n) raw[k] = __builtin_bswap64((uint64_t)__double_as_longlong(src[k]));
-        }
-    }
-}
-
-// ---- synthetic data (benchmark plumbing): splitmix64 counter RNG
-__device__ inline uint64_t splitmix64(uint64_t z) {
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-__device__ inline double u01(uint64_t bits) { return (double)(bits >> 11) * (1.0 / 9007199254740992.0); }
-
-__global__ __launch_bounds__(256) void k_fill_random(double* __restrict__ dst, int64_t n, uint64_t seed,
-                                                     uint64_t offset, int kind) {
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-        uint64_t ctr = (uint64_t)k + offset;
-        uint64_t h1 = splitmix64(seed ^ splitmix64(2 * ctr));
-        double u1 = u01(h1);
-        if (kind == 1) { dst[k] = u1; continue; }
-        uint64_t h2 = splitmix64(seed ^ splitmix64(2 * ctr + 1));
-        double u2 = u01(h2);
-        dst[k] = sqrt(-2.0 * log(1.0 - u1)) * cos(PXL_TWOPI_D * u2);   // Box-Muller
-    }
-}
-__global__ __launch_bounds__(256) void k_fill_sphere(double2* __restrict__ sky, int64_t n, uint64_t seed,
-                                                     uint64_t offset) {
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-        uint64_t ctr = (uint64_t)k + offset;
-        double u1 = u01(splitmix64(seed ^ splitmix64(2 * ctr)));
-        double u2 = u01(splitmix64(seed ^ splitmix64(2 * ctr + 1)));
-        sky[k] = make_double2(PXL_TWOPI_D * u1 - PXL_PI_D, asin(2.0 * u2 - 1.0));
-    }
-}
+#include "pxl_sample.h"
+#include "pxl_misc.h"
 
 // ================================================================================================
 // C ABI

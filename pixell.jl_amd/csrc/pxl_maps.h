@@ -1,0 +1,53 @@
+// pxl_maps.h -- whole-map writers: posmap and pixareamap; included by pxl_kernels.hip (one translation unit, -ffp-contract=off).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// posmap (A15) / pixareamap (N4): write-only maps.  Lane = 2 adjacent RA pixels (16 B stores).
+// ------------------------------------------------------------------------------------------------
+// Block = (512-column chunk, chunk of rows): RA (rewound) is computed once per lane and reused for every
+// row of the chunk; DEC / the row area is one evaluation per row.
+#define PXL_POS_ROWS 32
+__global__ __launch_bounds__(256) void k_posmap_car(CarAffine c, int64_t nx, int64_t row0, int64_t nrows,
+                                                    double* __restrict__ ra, double* __restrict__ dec, int safe) {
+    const bool vec = ((nx & 1) == 0) && ((((uintptr_t)ra | (uintptr_t)dec) & 15) == 0);
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;        // 0-based column of the pair
+    if (i >= nx) return;
+    double a0 = p2s_ra(c, (double)(i + 1));
+    double a1 = p2s_ra(c, (double)(i + 2));
+    if (safe) { a0 = rewind(a0, PXL_TWOPI_D, 0.0); a1 = rewind(a1, PXL_TWOPI_D, 0.0); }
+    const int64_t jr0 = (int64_t)blockIdx.y * PXL_POS_ROWS;
+    const int64_t jr1 = (jr0 + PXL_POS_ROWS < nrows) ? jr0 + PXL_POS_ROWS : nrows;
+    for (int64_t jr = jr0; jr < jr1; ++jr) {
+        double d = p2s_dec(c, (double)(row0 + jr + 1));
+        if (safe) d = rewind(d, PXL_TWOPI_D, 0.0);
+        int64_t o = jr * nx + i;
+        if (vec) {
+            *reinterpret_cast<double2*>(ra + o) = make_double2(a0, a1);
+            *reinterpret_cast<double2*>(dec + o) = make_double2(d, d);
+        } else {
+            ra[o] = a0; dec[o] = d;
+            if (i + 1 < nx) { ra[o + 1] = a1; dec[o + 1] = d; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pixareamap_car(CarAffine c, int64_t nx, int64_t row0, int64_t nrows,
+                                                        double* __restrict__ area) {
+    const bool vec = ((nx & 1) == 0) && (((uintptr_t)area & 15) == 0);
+    const double da = fabs(c.da);
+    // one row per blockIdx.y; the row value is computed once per lane and streamed along RA
+    const int64_t jr = blockIdx.y;
+    const double row = (double)(row0 + jr + 1);
+    // enmap_ops.jl:131-134: dec of the two pixel edges, sorted, clamped to the poles
+    double e0 = p2s_dec(c, row - 0.5), e1 = p2s_dec(c, row + 0.5);
+    double d1 = fmin(e0, e1), d2 = fmax(e0, e1);
+    d1 = fmax(-PXL_PI_D / 2, d1); d2 = fmin(PXL_PI_D / 2, d2);
+    const double v = (sin(d2) - sin(d1)) * da;
+    const int64_t npair = (nx + 1) / 2;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < npair; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i = t * 2;
+        int64_t o = jr * nx + i;
+        if (vec) *reinterpret_cast<double2*>(area + o) = make_double2(v, v);
+        else { area[o] = v; if (i + 1 < nx) area[o + 1] = v; }
+    }
+}
