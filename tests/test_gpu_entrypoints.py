@@ -36,3 +36,21 @@ def test_bench_contract(workload):
         assert d["check"]["bit_identical"] and d["check"]["max_abs_err"] == 0.0
         cb = d["cpu_baseline"]
         assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+
+
+def test_native_cpp_host(tmp_path):
+    """A host with no Python and no torch in it: tools/native/native_bench.cpp drives the C ABI with hipMalloc'ed
+    buffers (built with hipcc here, run as a child process)."""
+    import pixell_jl_amd as pj
+    libdir = os.path.dirname(pj.library_path())
+    exe = str(tmp_path / "native_bench")
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tools", "native", "native_bench.cpp"), "-L", libdir, "-lpixell_hip",
+           "-Wl,-rpath," + libdir, "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for args in (["2048", "2", "same", "3"], ["1024", "1", "refine", "3"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout, r.stderr)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d["native"] and d["kernel_ms"] > 0 and d["unity_err"] < 1e-13
