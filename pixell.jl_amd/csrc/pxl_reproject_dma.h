@@ -195,6 +195,19 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
     const bool vec_store = ((p.nxo & 1) == 0) && (((uintptr_t)p.dst & 15) == 0);
     double* orow = dplane + rb * p.nxo + c0 + 2 * lane;        // this lane's first output pair in row rb
 
+    if (p.flags & 64) {
+        // diagnostics: the tile's stores alone (no DMA, no LDS, no arithmetic) -- the write ceiling of this
+        // tile shape and order
+        for (int rr = 0; rr < nrows; ++rr) {
+#pragma unroll
+            for (int q = 0; q < PAIRS; ++q) {
+                double* o = orow + q * 128;
+                if (act[q][0]) *reinterpret_cast<double2*>(o) = make_double2(fx[q][0], fx[q][1]);
+            }
+            orow += p.nxo;
+        }
+        return;
+    }
     for (int rr = 0; rr < nrows; ++rr) {
         const int t0 = __builtin_amdgcn_readlane(my_t0, rr);
         const double fy = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_fy), rr),
