@@ -135,6 +135,12 @@ int pxl_reproject_execute(pxl_reproject_plan* plan, const double* src, double* d
 int pxl_reproject_build_tables(pxl_reproject_plan* plan, void* stream);
 int pxl_reproject_execute_rows(pxl_reproject_plan* plan, const double* src, double* dst,
                                int64_t r0, int64_t nr, void* stream);
+/* Float32 maps (Enmap{Float32}: the storage type most released maps use).  Same plan, same Float64 coordinate
+ * tables and weights; taps are widened to Float64, the result is rounded once to Float32 -- what Julia does when
+ * a Float64 expression is assigned into a Float32 array.                                                        */
+int pxl_reproject_execute_f32(pxl_reproject_plan* plan, const float* src, float* dst, void* stream);
+int pxl_reproject_execute_rows_f32(pxl_reproject_plan* plan, const float* src, float* dst,
+                                   int64_t r0, int64_t nr, void* stream);
 /* source rows [lo, hi) (0-based, absolute) that the plan's dst window reads (host computation,
  * same arithmetic as the device tables) -- what a shard must hold, i.e. strip + halo.               */
 int pxl_reproject_plan_src_rows(const pxl_reproject_plan* plan, int64_t* lo, int64_t* hi);
@@ -166,6 +172,10 @@ int pxl_reproject_generic_bilinear_f64(const pxl_car_wcs* wcs_in, int proj_in, c
 int pxl_sample_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], const double* src,
                                 int64_t src_row0, int64_t src_nrows,
                                 int64_t n, const double* sky2xN, double* out, void* stream);
+
+int pxl_sample_car_bilinear_f32(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], const float* src,
+                                int64_t src_row0, int64_t src_nrows,
+                                int64_t n, const double* sky2xN, float* out, void* stream);
 
 /* ---- FITS image staging (the on-disk format either side of the path: read_map / write_map, enmap.jl:198-237).
  *      raw_be: device copy of the HDU's big-endian data block, n elements of BITPIX -64 (or -32 for decode);

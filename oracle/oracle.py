@@ -258,3 +258,15 @@ def reproject_generic(wcs_in, proj_in, shape_in, src, wcs_out, proj_out, shape_o
         _i64((nxo, nyo)), _dp(dst))
     assert rc == 0
     return dst
+
+
+def reproject_f32(wcs_in, shape_in, src32, wcs_out, shape_out, **kw):
+    """Float32 maps: taps widened to Float64 (exact), the R1 arithmetic in Float64, one rounding to Float32 --
+    what Julia does when a Float64 expression is stored into a Float32 array."""
+    src32 = np.ascontiguousarray(src32, dtype=np.float32)
+    return reproject(wcs_in, shape_in, src32.astype(np.float64), wcs_out, shape_out, **kw).astype(np.float32)
+
+
+def sample_bilinear_f32(wcs_in, shape_in, src32, sky, **kw):
+    src32 = np.ascontiguousarray(src32, dtype=np.float32)
+    return sample_bilinear(wcs_in, shape_in, src32.astype(np.float64), sky, **kw).astype(np.float32)

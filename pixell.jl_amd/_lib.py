@@ -51,6 +51,8 @@ SIGNATURES = {
     "pxl_reproject_execute": (C.c_int, [_P, _P, _P, _P]),
     "pxl_reproject_build_tables": (C.c_int, [_P, _P]),
     "pxl_reproject_execute_rows": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),
+    "pxl_reproject_execute_f32": (C.c_int, [_P, _P, _P, _P]),
+    "pxl_reproject_execute_rows_f32": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),
     "pxl_reproject_plan_src_rows": (C.c_int, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
     "pxl_reproject_plan_rows_covered": (C.c_int, [_P, _I64, _I64, C.POINTER(_I64), C.POINTER(_I64)]),
     "pxl_reproject_plan_set_variant": (C.c_int, [_P, C.c_int]),
@@ -58,6 +60,7 @@ SIGNATURES = {
     "pxl_reproject_car_bilinear_f64": (C.c_int, [_WP, _SHP, _P, _WP, _SHP, _P, _P]),
     "pxl_reproject_generic_bilinear_f64": (C.c_int, [_WP, C.c_int, _SHP, _P, _WP, C.c_int, _SHP, _P, _P]),
     "pxl_sample_car_bilinear_f64": (C.c_int, [_WP, _SHP, _P, _I64, _I64, _I64, _P, _P, _P]),
+    "pxl_sample_car_bilinear_f32": (C.c_int, [_WP, _SHP, _P, _I64, _I64, _I64, _P, _P, _P]),
     "pxl_fits_decode_f64": (C.c_int, [_P, _P, _I64, C.c_int, _P]),
     "pxl_fits_encode_f64": (C.c_int, [_P, _P, _I64, _P]),
     "pxl_fill_random_f64": (C.c_int, [_P, _I64, C.c_uint64, C.c_uint64, C.c_int, _P]),

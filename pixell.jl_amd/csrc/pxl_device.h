@@ -85,21 +85,26 @@ __host__ __device__ inline void split_cell(double x, int32_t* cell, double* frac
 }
 
 // Source map view used by the direct-gather paths (oracle: tap()/bilerp() in oracle/pixell_oracle.c).
-struct SrcView {
-    const double* plane;   // first resident row of this component plane
+// T is the STORAGE type of the map (double, or float for Float32 maps); arithmetic is always Float64.
+template <typename T>
+struct SrcViewT {
+    const T* plane;        // first resident row of this component plane
     int64_t nx, ny;        // full map size
     int64_t row0, nrows;   // resident rows [row0, row0 + nrows), 0-based
     int periodic;          // RA taps wrap modulo nx
 };
-__device__ inline double tap(const SrcView& m, int64_t i, int64_t j) {   // i, j 1-based
+using SrcView = SrcViewT<double>;
+template <typename T>
+__device__ inline double tap(const SrcViewT<T>& m, int64_t i, int64_t j) {   // i, j 1-based
     if (j < 1 || j > m.ny) return 0.0;
     int64_t jr = j - 1 - m.row0;
     if (jr < 0 || jr >= m.nrows) return 0.0;
     if (m.periodic) { i = (i - 1) % m.nx; if (i < 0) i += m.nx; i += 1; }
     else if (i < 1 || i > m.nx) return 0.0;
-    return m.plane[jr * m.nx + (i - 1)];
+    return (double)m.plane[jr * m.nx + (i - 1)];
 }
-__device__ inline double bilerp_cells(const SrcView& m, int64_t i0, double fx, int64_t j0, double fy) {
+template <typename T>
+__device__ inline double bilerp_cells(const SrcViewT<T>& m, int64_t i0, double fx, int64_t j0, double fy) {
     double top = (1 - fx) * tap(m, i0, j0) + fx * tap(m, i0 + 1, j0);
     double bot = (1 - fx) * tap(m, i0, j0 + 1) + fx * tap(m, i0 + 1, j0 + 1);
     return (1 - fy) * top + fy * bot;

@@ -97,6 +97,9 @@ struct pxl_reproject_plan {
     int pairs;         // lane width of the register-staged kernel: 1 or 2 (x2 output columns per lane)
     int pairs_dma;     // lane width of the LDS-DMA kernel: 1, 2 or 4
     int seg_dma;
+    int pairs_dma32;   // the same for Float32 storage (4 elements per lane per access)
+    int seg_dma32;
+    bool dma32_ok;
     int dypos;
     int rh;
     int seg;
@@ -423,6 +426,18 @@ int pxl_reproject_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[
     auto stageable = [&](int64_t sg) { return (sg <= max_seg) && !(pl->periodic && sg > pl->nx) && sy <= 3.0; };
     pl->staged_ok = stageable(seg) && stageable(seg_for(pl->pairs_dma));
     pl->seg = (int)(seg <= max_seg ? seg : max_seg);
+    {   // Float32 storage: a wave access covers 256 elements, slots hold up to 5 x 256
+        const int max_seg32 = PXL_MAXCH * 256;
+        auto seg_for32 = [&](int pairs) -> int64_t {
+            double span = ceil((double)(256 * pairs) * sx) + 8.0;      // + taps, rounding and up to 3 of alignment
+            return ((int64_t)span + 3) & ~(int64_t)3;
+        };
+        pl->pairs_dma32 = want;
+        while (pl->pairs_dma32 > 1 && seg_for32(pl->pairs_dma32) > max_seg32) pl->pairs_dma32 >>= 1;
+        int64_t s32 = seg_for32(pl->pairs_dma32);
+        pl->dma32_ok = (s32 <= max_seg32) && !(pl->periodic && s32 > pl->nx) && sy <= 3.0 && (pl->nx % 4 == 0);
+        pl->seg_dma32 = (int)std::min<int64_t>(s32, max_seg32);
+    }
     pl->vec_load = (pl->nx % 2 == 0);
     *out = pl;
     return PXL_OK;
@@ -453,14 +468,16 @@ int pxl_reproject_build_tables(pxl_reproject_plan* pl, void* stream) {
     return rc;
 }
 
-int pxl_reproject_execute_rows(pxl_reproject_plan* pl, const double* src, double* dst, int64_t r0, int64_t nr,
-                               void* stream) {
+// dtype: 8 = Float64 storage, 4 = Float32 storage (coordinates and weights are Float64 either way)
+static int reproject_rows_impl(pxl_reproject_plan* pl, const void* src, void* dst, int64_t r0, int64_t nr,
+                               void* stream, int dtype) {
     if (!pl) return fail(PXL_EINVAL, "execute: null plan");
     if (r0 < 0 || nr < 0 || r0 + nr > pl->dst_nrows) return fail(PXL_EINVAL, "execute: rows outside the dst window");
     if (nr == 0) return PXL_OK;
     if (!dst || (!src && pl->src_nrows > 0)) return fail(PXL_EINVAL, "execute: null src/dst");
     if (!pl->tables_built) return fail(PXL_EINVAL, "execute_rows: tables not built");
     hipStream_t st = (hipStream_t)stream;
+    const bool f32 = dtype == 4;
 
     ReprojParams p;
     memset(&p, 0, sizeof(p));
@@ -470,19 +487,24 @@ int pxl_reproject_execute_rows(pxl_reproject_plan* pl, const double* src, double
     p.nxo = pl->nxo; p.dst_row0 = pl->dst_row0; p.dst_nrows = pl->dst_nrows;
     p.r0 = r0; p.nr = nr; p.nc = (int32_t)pl->nc; p.periodic = pl->periodic;
 
-    bool staged = pl->staged_ok;
+    const bool aligned = (((uintptr_t)src & 15) == 0);
+    bool staged = f32 ? (pl->dma32_ok && aligned) : pl->staged_ok;
     if (pl->variant == 1) staged = false;
     if (!staged) {
         int64_t work = ((pl->nxo + 1) / 2) * nr;
-        hipLaunchKernelGGL(k_reproject_gather, dim3(stream_grid(work, 256), (unsigned)pl->nc), dim3(256), 0, st, p);
+        dim3 g(stream_grid(work, 256), (unsigned)pl->nc);
+        if (f32) hipLaunchKernelGGL((k_reproject_gather<float>), g, dim3(256), 0, st, p);
+        else     hipLaunchKernelGGL((k_reproject_gather<double>), g, dim3(256), 0, st, p);
         return check_launch("k_reproject_gather");
     }
 
-    const bool vec = pl->vec_load && (((uintptr_t)src & 15) == 0);
-    const bool use_dma = vec && pl->variant != 2;
-    const int pairs = use_dma ? pl->pairs_dma : pl->pairs;
-    const int TW = 128 * pairs;
-    p.seg = use_dma ? pl->seg_dma : pl->seg; p.dxpos = pl->dxpos; p.dypos = pl->dypos; p.flags = pl->flags;
+    const bool vec = f32 ? true : (pl->vec_load && aligned);
+    const bool use_dma = f32 ? true : (vec && pl->variant != 2);
+    const int pairs = f32 ? pl->pairs_dma32 : (use_dma ? pl->pairs_dma : pl->pairs);
+    const int cw = f32 ? 256 : 128;                   // elements per wave access
+    const int TW = cw * pairs;
+    p.seg = f32 ? pl->seg_dma32 : (use_dma ? pl->seg_dma : pl->seg);
+    p.dxpos = pl->dxpos; p.dypos = pl->dypos; p.flags = pl->flags;
     p.ntx = (int32_t)((pl->nxo + TW - 1) / TW);
     // tile height: the configured rh, halved while the launch would leave the chip short of waves
     // (256 CUs x ~16 resident waves, a few rounds each); small maps and thin strips get shorter tiles
@@ -497,10 +519,13 @@ int pxl_reproject_execute_rows(pxl_reproject_plan* pl, const double* src, double
     dim3 grid((unsigned)nblocks), block(64);
     if (use_dma) {
         // LDS-DMA fast path; shrink the ring if it would not fit a CU's LDS comfortably
+        const size_t esz = f32 ? 4 : 8;
         p.ns = pl->ns; p.pf = pl->pf; p.zero_page = pl->zero_page;
-        while ((size_t)p.ns * p.seg * 8 > 17 * 1024 && p.ns > 4) p.ns >>= 1;    // keep >= 9 waves per CU
-        size_t dma_lds = (size_t)p.ns * (size_t)p.seg * sizeof(double);
-        return launch_reproject_dma(pairs, (p.seg + 127) / 128, grid, dma_lds, (hipStream_t)stream, p);
+        while ((size_t)p.ns * p.seg * esz > 17 * 1024 && p.ns > 4) p.ns >>= 1;    // keep >= 9 waves per CU
+        size_t dma_lds = (size_t)p.ns * (size_t)p.seg * esz;
+        const int nch = (p.seg + cw - 1) / cw;
+        if (f32) return launch_reproject_dma_t<float>(pairs, nch, grid, dma_lds, st, p);
+        return launch_reproject_dma_t<double>(pairs, nch, grid, dma_lds, st, p);
     }
     size_t lds_bytes = (size_t)PXL_NS * (size_t)pl->seg * sizeof(double);
     if (pl->pairs == 2) {
@@ -513,10 +538,26 @@ int pxl_reproject_execute_rows(pxl_reproject_plan* pl, const double* src, double
     return check_launch("k_reproject_staged");
 }
 
+int pxl_reproject_execute_rows(pxl_reproject_plan* pl, const double* src, double* dst, int64_t r0, int64_t nr,
+                               void* stream) {
+    return reproject_rows_impl(pl, src, dst, r0, nr, stream, 8);
+}
+
+int pxl_reproject_execute_rows_f32(pxl_reproject_plan* pl, const float* src, float* dst, int64_t r0, int64_t nr,
+                                   void* stream) {
+    return reproject_rows_impl(pl, src, dst, r0, nr, stream, 4);
+}
+
 int pxl_reproject_execute(pxl_reproject_plan* pl, const double* src, double* dst, void* stream) {
     int rc = pxl_reproject_build_tables(pl, stream);
     if (rc) return rc;
     return pxl_reproject_execute_rows(pl, src, dst, 0, pl->dst_nrows, stream);
+}
+
+int pxl_reproject_execute_f32(pxl_reproject_plan* pl, const float* src, float* dst, void* stream) {
+    int rc = pxl_reproject_build_tables(pl, stream);
+    if (rc) return rc;
+    return pxl_reproject_execute_rows_f32(pl, src, dst, 0, pl->dst_nrows, stream);
 }
 
 int pxl_reproject_plan_src_rows(const pxl_reproject_plan* pl, int64_t* lo, int64_t* hi) {
@@ -596,9 +637,8 @@ int pxl_reproject_generic_bilinear_f64(const pxl_car_wcs* wcs_in, int proj_in, c
     return check_launch("k_reproject_generic");
 }
 
-int pxl_sample_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], const double* src,
-                                int64_t src_row0, int64_t src_nrows, int64_t n, const double* sky, double* out,
-                                void* stream) {
+static int sample_impl(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], const void* src, int64_t src_row0,
+                       int64_t src_nrows, int64_t n, const double* sky, void* out, void* stream, int dtype) {
     if (!wcs_ok(wcs_in) || !shape_in) return fail(PXL_EINVAL, "sample: invalid WCS/shape");
     if (shape_in[0] < 1 || shape_in[1] < 1 || shape_in[2] < 1) return fail(PXL_EINVAL, "sample: shapes must be positive");
     if (src_row0 < 0 || src_nrows < 0 || src_row0 + src_nrows > shape_in[1])
@@ -608,10 +648,28 @@ int pxl_sample_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shape_i
     if (n == 0) return PXL_OK;
     Sky2Pix s = sky2pix_setup(*wcs_in, shape_in[0], shape_in[1], 1, PXL_FORM_RECIP);
     int periodic = fabs((double)shape_in[0] * fabs(wcs_in->cdelt[0] * wcs_in->unit) - PXL_TWOPI_D) < 1e-8;
-    hipLaunchKernelGGL(k_sample_bilinear, dim3(stream_grid((n + PXL_SUNR - 1) / PXL_SUNR, 256)), dim3(256), 0,
-                       (hipStream_t)stream, s, src, shape_in[0], shape_in[1], (int32_t)shape_in[2], src_row0, src_nrows,
-                       periodic, n, (const double2*)sky, out);
+    dim3 grid(stream_grid((n + PXL_SUNR - 1) / PXL_SUNR, 256));
+    if (dtype == 4)
+        hipLaunchKernelGGL((k_sample_bilinear<float>), grid, dim3(256), 0, (hipStream_t)stream, s, (const float*)src,
+                           shape_in[0], shape_in[1], (int32_t)shape_in[2], src_row0, src_nrows, periodic, n,
+                           (const double2*)sky, (float*)out);
+    else
+        hipLaunchKernelGGL((k_sample_bilinear<double>), grid, dim3(256), 0, (hipStream_t)stream, s, (const double*)src,
+                           shape_in[0], shape_in[1], (int32_t)shape_in[2], src_row0, src_nrows, periodic, n,
+                           (const double2*)sky, (double*)out);
     return check_launch("k_sample_bilinear");
+}
+
+int pxl_sample_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], const double* src,
+                                int64_t src_row0, int64_t src_nrows, int64_t n, const double* sky, double* out,
+                                void* stream) {
+    return sample_impl(wcs_in, shape_in, src, src_row0, src_nrows, n, sky, out, stream, 8);
+}
+
+int pxl_sample_car_bilinear_f32(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], const float* src,
+                                int64_t src_row0, int64_t src_nrows, int64_t n, const double* sky, float* out,
+                                void* stream) {
+    return sample_impl(wcs_in, shape_in, src, src_row0, src_nrows, n, sky, out, stream, 4);
 }
 
 int pxl_fits_decode_f64(const void* raw_be, double* dst, int64_t n, int bitpix, void* stream) {

@@ -24,8 +24,8 @@ __global__ __launch_bounds__(256) void k_build_tables(CarAffine out, Sky2Pix in,
 }
 
 struct ReprojParams {
-    const double* src;     // (nx, src_nrows, nc)
-    double* dst;           // (nxo, dst_nrows, nc)
+    const void* src;       // (nx, src_nrows, nc), Float64 or Float32 storage
+    void* dst;             // (nxo, dst_nrows, nc), same storage type
     const int32_t* xi0; const double* xfx;   // nxo entries
     const int32_t* yj0; const double* yfy;   // nyo entries (absolute output row)
     int64_t nx, ny, src_row0, src_nrows;
@@ -48,13 +48,13 @@ struct ReprojParams {
 // ---- generic direct-gather kernel: one lane per output pixel pair, 4 taps from global memory each.
 //      Used when a tile's source footprint does not fit the LDS ring (large down-scaling) and as the
 //      cross-check variant.
+template <typename T>
 __global__ __launch_bounds__(256) void k_reproject_gather(ReprojParams p) {
     const int64_t npair = (p.nxo + 1) / 2;
     const int64_t total = npair * p.nr;
     const int c = blockIdx.y;
-    SrcView m{p.src + (int64_t)c * p.nx * p.src_nrows, p.nx, p.ny, p.src_row0, p.src_nrows, p.periodic};
-    double* dplane = p.dst + (int64_t)c * p.nxo * p.dst_nrows;
-    const bool vec = ((p.nxo & 1) == 0) && (((uintptr_t)p.dst & 15) == 0);
+    SrcViewT<T> m{(const T*)p.src + (int64_t)c * p.nx * p.src_nrows, p.nx, p.ny, p.src_row0, p.src_nrows, p.periodic};
+    T* dplane = (T*)p.dst + (int64_t)c * p.nxo * p.dst_nrows;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
         int64_t rr = t / npair;
@@ -62,15 +62,9 @@ __global__ __launch_bounds__(256) void k_reproject_gather(ReprojParams p) {
         int64_t r = p.r0 + rr;
         int64_t j0 = p.yj0[p.dst_row0 + r];
         double fy = p.yfy[p.dst_row0 + r];
-        double v0 = bilerp_cells(m, p.xi0[i], p.xfx[i], j0, fy);
         int64_t o = r * p.nxo + i;
-        if (i + 1 < p.nxo) {
-            double v1 = bilerp_cells(m, p.xi0[i + 1], p.xfx[i + 1], j0, fy);
-            if (vec) *reinterpret_cast<double2*>(dplane + o) = make_double2(v0, v1);
-            else { dplane[o] = v0; dplane[o + 1] = v1; }
-        } else {
-            dplane[o] = v0;
-        }
+        dplane[o] = (T)bilerp_cells(m, p.xi0[i], p.xfx[i], j0, fy);
+        if (i + 1 < p.nxo) dplane[o + 1] = (T)bilerp_cells(m, p.xi0[i + 1], p.xfx[i + 1], j0, fy);
     }
 }
 
@@ -151,8 +145,8 @@ __global__ __launch_bounds__(64) void k_reproject_staged(ReprojParams p) {
     const int ty = (int)(trest % p.nty);
     const int c = (int)(trest / p.nty);
 
-    const double* splane = p.src + (int64_t)c * p.nx * p.src_nrows;
-    double* dplane = p.dst + (int64_t)c * p.nxo * p.dst_nrows;
+    const double* splane = (const double*)p.src + (int64_t)c * p.nx * p.src_nrows;
+    double* dplane = (double*)p.dst + (int64_t)c * p.nxo * p.dst_nrows;
 
     const int64_t c0 = (int64_t)tx * TW;                       // first output column of the tile
     const int64_t clast = (c0 + TW < p.nxo ? c0 + TW : p.nxo) - 1;

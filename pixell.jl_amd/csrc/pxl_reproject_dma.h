@@ -54,11 +54,15 @@ __device__ __forceinline__ void glds16_vaddr(const void* gsrc, uint32_t lds_byte
                  :: "v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
 
-template <int PAIRS, int NCH>
+// T = storage type of the maps (double or float); EPL = elements per lane per 16-byte access.
+template <typename T, int PAIRS, int NCH>
 __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];   // ns * seg doubles
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];   // ns * seg elements of T
+    T* const lds = reinterpret_cast<T*>(lds_raw);
     const int lane = threadIdx.x;
-    constexpr int TW = 128 * PAIRS;
+    constexpr int EPL = 16 / (int)sizeof(T);       // 2 doubles or 4 floats per lane per access
+    constexpr int CW = 64 * EPL;                   // elements per wave access (1 KiB)
+    constexpr int TW = CW * PAIRS;                 // output columns per tile
 
     // XCD-aware decode: blocks b and b+8 share an XCD; give each XCD a contiguous run of tiles so that
     // RA-neighbouring tiles (shared 128-B lines at the edges, same source rows) meet in one L2.
@@ -72,8 +76,8 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
     const int ty = (int)(trest % p.nty);
     const int c = (int)(trest / p.nty);
 
-    const double* splane = p.src + (int64_t)c * p.nx * p.src_nrows;
-    double* dplane = p.dst + (int64_t)c * p.nxo * p.dst_nrows;
+    const T* splane = (const T*)p.src + (int64_t)c * p.nx * p.src_nrows;
+    T* dplane = (T*)p.dst + (int64_t)c * p.nxo * p.dst_nrows;
 
     const int64_t c0 = (int64_t)tx * TW;
     const int64_t clast = (c0 + TW < p.nxo ? c0 + TW : p.nxo) - 1;
@@ -84,16 +88,16 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
     // ---- per-lane column setup (constant over the tile)
     const int64_t a = p.dxpos ? p.xi0[c0] : p.xi0[clast];      // 1-based source cell at the tile's low end
     const int64_t ua = a - 1;
-    const int64_t cbase0 = ua & ~(int64_t)1;                   // even 0-based source column at slot index 0
-    int dloc[PAIRS][2];
-    double fx[PAIRS][2];
-    bool act[PAIRS][2];
+    const int64_t cbase0 = ua - (((ua % EPL) + EPL) % EPL);    // 0-based source column at slot index 0 (16-B aligned)
+    int dloc[PAIRS][EPL];
+    double fx[PAIRS][EPL];
+    bool act[PAIRS][EPL];
     bool fits = true;
 #pragma unroll
     for (int q = 0; q < PAIRS; ++q) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            int64_t col = c0 + q * 128 + 2 * lane + e;
+        for (int e = 0; e < EPL; ++e) {
+            int64_t col = c0 + q * CW + EPL * lane + e;
             act[q][e] = col < p.nxo;
             int64_t i0 = act[q][e] ? p.xi0[col] : a;
             fx[q][e] = act[q][e] ? p.xfx[col] : 0.0;
@@ -119,16 +123,16 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
 
     if (!__all(fits)) {
         // wave-uniform fallback: direct taps (rewind discontinuity inside the tile)
-        SrcView m{splane, p.nx, p.ny, p.src_row0, p.src_nrows, p.periodic};
+        SrcViewT<T> m{splane, p.nx, p.ny, p.src_row0, p.src_nrows, p.periodic};
         for (int64_t r = rb; r < re; ++r) {
             int64_t j0 = p.yj0[p.dst_row0 + r];
             double fy = p.yfy[p.dst_row0 + r];
 #pragma unroll
             for (int q = 0; q < PAIRS; ++q)
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    int64_t col = c0 + q * 128 + 2 * lane + e;
-                    if (act[q][e]) dplane[r * p.nxo + col] = bilerp_cells(m, p.xi0[col], fx[q][e], j0, fy);
+                for (int e = 0; e < EPL; ++e) {
+                    int64_t col = c0 + q * CW + EPL * lane + e;
+                    if (act[q][e]) dplane[r * p.nxo + col] = (T)bilerp_cells(m, p.xi0[col], fx[q][e], j0, fy);
                 }
         }
         return;
@@ -139,15 +143,15 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
     uint32_t voff[NCH];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-        int64_t u = cbase0 + ch * 128 + 2 * lane;
+        int64_t u = cbase0 + ch * CW + EPL * lane;
         bool ok = true;
         if (p.periodic) { u %= p.nx; if (u < 0) u += p.nx; }
         else ok = (u >= 0) && (u < p.nx);
-        voff[ch] = ok ? (uint32_t)(u * 8) : 0xFFFFFFFFu;
+        voff[ch] = ok ? (uint32_t)(u * (int64_t)sizeof(T)) : 0xFFFFFFFFu;
     }
 
     const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
-    const uint32_t slot_bytes = (uint32_t)p.seg * 8u;
+    const uint32_t slot_bytes = (uint32_t)p.seg * (uint32_t)sizeof(T);
     const int ns_mask = p.ns - 1;
 
     // ---- request bookkeeping (all wave-uniform).  Rows are requested strictly in t order, so the row
@@ -160,11 +164,11 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
             if (p.dypos) { tv_lo = (int)jlo; tv_hi = (int)jhi; } else { tv_lo = -(int)jhi; tv_hi = -(int)jlo; }
         }
     }
-    const int64_t row_step = (int64_t)dir * p.nx * 8;           // bytes from row t to row t + 1
+    const int64_t row_step = (int64_t)dir * p.nx * (int64_t)sizeof(T);   // bytes from row t to row t + 1
     int treq = __builtin_amdgcn_readlane(my_t0, 0) - 1;         // nothing requested yet
-    const char* next_row = (const char*)splane + ((int64_t)dir * (treq + 1) - 1 - p.src_row0) * p.nx * 8;
-    const bool tail_full = (p.seg == NCH * 128);
-    const bool in_tail = ((NCH - 1) * 128 + 2 * lane) < p.seg;  // lanes of the last chunk inside the slot
+    const char* next_row = (const char*)splane + ((int64_t)dir * (treq + 1) - 1 - p.src_row0) * p.nx * (int64_t)sizeof(T);
+    const bool tail_full = (p.seg == NCH * CW);
+    const bool in_tail = ((NCH - 1) * CW + EPL * lane) < p.seg;  // lanes of the last chunk inside the slot
     const uint32_t zero_off = 0u;
 
     auto issue_next = [&]() {           // request source row t = treq + 1 into slot t & ns_mask
@@ -192,8 +196,8 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
         next_row += row_step;
     };
 
-    const bool vec_store = ((p.nxo & 1) == 0) && (((uintptr_t)p.dst & 15) == 0);
-    double* orow = dplane + rb * p.nxo + c0 + 2 * lane;        // this lane's first output pair in row rb
+    const bool vec_store = ((p.nxo % EPL) == 0) && (((uintptr_t)p.dst & 15) == 0);
+    T* orow = dplane + rb * p.nxo + c0 + EPL * lane;           // this lane's first output group in row rb
 
     if (p.flags & 64) {
         // diagnostics: the tile's stores alone (no DMA, no LDS, no arithmetic) -- the write ceiling of this
@@ -201,8 +205,11 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
         for (int rr = 0; rr < nrows; ++rr) {
 #pragma unroll
             for (int q = 0; q < PAIRS; ++q) {
-                double* o = orow + q * 128;
-                if (act[q][0]) *reinterpret_cast<double2*>(o) = make_double2(fx[q][0], fx[q][1]);
+                T* o = orow + q * CW;
+                alignas(16) T v[EPL];
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) v[e] = (T)fx[q][e];
+                if (act[q][0] && vec_store) *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(v);
             }
             orow += p.nxo;
         }
@@ -224,24 +231,27 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
 
         const int st = (p.dypos ? t0 : t0 + 1) & ns_mask;      // slot of source row j0 (top)
         const int sb = (p.dypos ? t0 + 1 : t0) & ns_mask;      // slot of source row j0 + 1 (bottom)
-        const double* T = lds + st * p.seg;
-        const double* B = lds + sb * p.seg;
+        const T* Tp = lds + st * p.seg;
+        const T* Bp = lds + sb * p.seg;
         const double wy = 1 - fy;
 #pragma unroll
         for (int q = 0; q < PAIRS; ++q) {
-            double v[2];
+            alignas(16) T v[EPL];
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
+            for (int e = 0; e < EPL; ++e) {
                 const int d = dloc[q][e];
                 const double wx = 1 - fx[q][e];
-                const double top = wx * T[d] + fx[q][e] * T[d + 1];
-                const double bot = wx * B[d] + fx[q][e] * B[d + 1];
-                v[e] = wy * top + fy * bot;
+                const double top = wx * (double)Tp[d] + fx[q][e] * (double)Tp[d + 1];
+                const double bot = wx * (double)Bp[d] + fx[q][e] * (double)Bp[d + 1];
+                v[e] = (T)(wy * top + fy * bot);
             }
-            double* o = orow + q * 128;
-            if (p.flags & 2) { if (v[0] == 1.2345e300) o[0] = v[1]; }       // diagnostics: keep v live, never store
-            else if (vec_store) { if (act[q][0]) *reinterpret_cast<double2*>(o) = make_double2(v[0], v[1]); }
-            else { if (act[q][0]) o[0] = v[0]; if (act[q][1]) o[1] = v[1]; }
+            T* o = orow + q * CW;
+            if (p.flags & 2) { if (v[0] == (T)1.2345e30) o[0] = v[1]; }       // diagnostics: keep v live, never store
+            else if (vec_store) { if (act[q][0]) *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(v); }
+            else {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) if (act[q][e]) o[e] = v[e];
+            }
         }
         orow += p.nxo;
         // the LDS reads above have returned (their values were consumed); make that explicit before a
@@ -250,9 +260,10 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
     }
 }
 
-static int launch_reproject_dma(int pairs, int nch, dim3 grid, size_t lds_bytes, hipStream_t st, const ReprojParams& p) {
+template <typename T>
+static int launch_reproject_dma_t(int pairs, int nch, dim3 grid, size_t lds_bytes, hipStream_t st, const ReprojParams& p) {
 #define PXL_DMA_CASE(P, N) \
-    if (pairs == P && nch == N) { hipLaunchKernelGGL((k_reproject_dma<P, N>), grid, dim3(64), lds_bytes, st, p); return check_launch("k_reproject_dma"); }
+    if (pairs == P && nch == N) { hipLaunchKernelGGL((k_reproject_dma<T, P, N>), grid, dim3(64), lds_bytes, st, p); return check_launch("k_reproject_dma"); }
     PXL_DMA_CASE(1, 1) PXL_DMA_CASE(1, 2) PXL_DMA_CASE(1, 3) PXL_DMA_CASE(1, 4) PXL_DMA_CASE(1, 5)
     PXL_DMA_CASE(2, 1) PXL_DMA_CASE(2, 2) PXL_DMA_CASE(2, 3) PXL_DMA_CASE(2, 4) PXL_DMA_CASE(2, 5)
     PXL_DMA_CASE(4, 1) PXL_DMA_CASE(4, 2) PXL_DMA_CASE(4, 3) PXL_DMA_CASE(4, 4) PXL_DMA_CASE(4, 5)

@@ -50,10 +50,11 @@ __device__ inline int64_t wrap_col(int64_t i, int64_t nx) {          // 1-based 
     if (i >= 1 - nx && i <= 2 * nx) { if (i > nx) i -= nx; else if (i < 1) i += nx; return i; }
     i = (i - 1) % nx; if (i < 0) i += nx; return i + 1;
 }
-__global__ __launch_bounds__(256) void k_sample_bilinear(Sky2Pix s, const double* __restrict__ src, int64_t nx,
+template <typename T>
+__global__ __launch_bounds__(256) void k_sample_bilinear(Sky2Pix s, const T* __restrict__ src, int64_t nx,
                                                          int64_t ny, int32_t nc, int64_t row0, int64_t nrows,
                                                          int periodic, int64_t n, const double2* __restrict__ sky,
-                                                         double* __restrict__ out) {
+                                                         T* __restrict__ out) {
     const int64_t chunk = (int64_t)blockDim.x * PXL_SUNR;
     const int64_t plane = nx * nrows;
     for (int64_t k0 = (int64_t)blockIdx.x * chunk + threadIdx.x; k0 < n; k0 += (int64_t)gridDim.x * chunk) {
@@ -86,14 +87,14 @@ __global__ __launch_bounds__(256) void k_sample_bilinear(Sky2Pix s, const double
             o11[u] = (rowb && okb) ? jb * nx + (ib - 1) : -1;
         }
         for (int c = 0; c < nc; ++c) {
-            const double* pl = src + (int64_t)c * plane;
+            const T* pl = src + (int64_t)c * plane;
             double m00[PXL_SUNR], m10[PXL_SUNR], m01[PXL_SUNR], m11[PXL_SUNR];
 #pragma unroll
             for (int u = 0; u < PXL_SUNR; ++u) {
-                m00[u] = o00[u] >= 0 ? pl[o00[u]] : 0.0;
-                m10[u] = o10[u] >= 0 ? pl[o10[u]] : 0.0;
-                m01[u] = o01[u] >= 0 ? pl[o01[u]] : 0.0;
-                m11[u] = o11[u] >= 0 ? pl[o11[u]] : 0.0;
+                m00[u] = o00[u] >= 0 ? (double)pl[o00[u]] : 0.0;
+                m10[u] = o10[u] >= 0 ? (double)pl[o10[u]] : 0.0;
+                m01[u] = o01[u] >= 0 ? (double)pl[o01[u]] : 0.0;
+                m11[u] = o11[u] >= 0 ? (double)pl[o11[u]] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < PXL_SUNR; ++u) {
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void k_sample_bilinear(Sky2Pix s, const double
                 double top = (1 - fx[u]) * m00[u] + fx[u] * m10[u];
                 double bot = (1 - fx[u]) * m01[u] + fx[u] * m11[u];
                 double v = (1 - fy[u]) * top + fy[u] * bot;
-                if (k < n) out[(int64_t)c * n + k] = fin[u] ? v : __builtin_nan("");
+                if (k < n) out[(int64_t)c * n + k] = (T)(fin[u] ? v : __builtin_nan(""));
             }
         }
     }

@@ -43,6 +43,17 @@ def _dev_f64(t: torch.Tensor, what: str) -> torch.Tensor:
     return t
 
 
+def _dev_map(t: torch.Tensor, what: str) -> torch.Tensor:
+    """Map storage may be Float64 or Float32 (coordinates are always Float64)."""
+    if isinstance(t, torch.Tensor) and t.dtype == torch.float32:
+        if not t.is_cuda:
+            raise RuntimeError("%s must live on the GPU: the MI355X path has no CPU fallback" % what)
+        if not t.is_contiguous():
+            raise ValueError("%s must be contiguous" % what)
+        return t
+    return _dev_f64(t, what)
+
+
 def _ptr(t: torch.Tensor):
     return C.c_void_p(t.data_ptr())
 
@@ -312,7 +323,9 @@ class ReprojectPlan:
         return lo.value, hi.value
 
     def _check(self, src, dst):
-        src, dst = _dev_f64(src, "src"), _dev_f64(dst, "dst")
+        src, dst = _dev_map(src, "src"), _dev_map(dst, "dst")
+        if src.dtype != dst.dtype:
+            raise TypeError("src and dst must have the same dtype (Float64 or Float32)")
         if src.numel() != self.ncomp * self.src_rows[1] * self.shape_in[0]:
             raise ValueError("src has %d elements, plan expects %s" % (src.numel(), (self.src_tensor_shape(),)))
         if dst.numel() != self.ncomp * self.dst_rows[1] * self.shape_out[0]:
@@ -323,8 +336,10 @@ class ReprojectPlan:
 
     def execute(self, src, dst):
         src, dst = self._check(src, dst)
+        lib = _lib.load()
+        fn = lib.pxl_reproject_execute_f32 if src.dtype == torch.float32 else lib.pxl_reproject_execute
         with torch.cuda.device(self.device):
-            _lib.check(_lib.load().pxl_reproject_execute(self._h, _ptr(src), _ptr(dst), _stream(dst)))
+            _lib.check(fn(self._h, _ptr(src), _ptr(dst), _stream(dst)))
         return dst
 
     def build_tables(self):
@@ -334,8 +349,10 @@ class ReprojectPlan:
 
     def execute_rows(self, src, dst, r0, nr):
         src, dst = self._check(src, dst)
+        lib = _lib.load()
+        fn = lib.pxl_reproject_execute_rows_f32 if src.dtype == torch.float32 else lib.pxl_reproject_execute_rows
         with torch.cuda.device(self.device):
-            _lib.check(_lib.load().pxl_reproject_execute_rows(self._h, _ptr(src), _ptr(dst), r0, nr, _stream(dst)))
+            _lib.check(fn(self._h, _ptr(src), _ptr(dst), r0, nr, _stream(dst)))
         return dst
 
     def close(self):
@@ -360,7 +377,7 @@ def reproject(m: Enmap, shape_out, wcs_out, out: Enmap = None, plan: ReprojectPl
         plan = ReprojectPlan(m.shape, m.wcs, shape_out, wcs_out, device=m.device)
     if out is None:
         oshape = (nyo, nxo) if m.data.dim() == 2 else (m.data.shape[0], nyo, nxo)
-        out = Enmap(torch.empty(oshape, dtype=torch.float64, device=m.device), wcs_out)
+        out = Enmap(torch.empty(oshape, dtype=m.data.dtype, device=m.device), wcs_out)
     plan.execute(m.data, out.data)
     return out
 
@@ -388,14 +405,16 @@ def sample_bilinear(m: Enmap, skycoords: torch.Tensor, src_rows=None, full_shape
     sky2pix!(safe=true) [car_proj.jl:165-193] + 2x2 gather.  Returns a (nc, N) tensor.
     src_rows/full_shape describe `m.data` as a declination strip of a larger map."""
     sky = _dev_f64(skycoords, "skycoords")
-    data = _dev_f64(m.data, "map data")
+    data = _dev_map(m.data, "map data")
     _require_car(m.wcs)
     shape = m.shape if full_shape is None else tuple(full_shape)
     nc = data.shape[0] if data.dim() == 3 else 1
     row0, nrows = (0, shape[1]) if src_rows is None else src_rows
-    out = torch.empty((nc, sky.shape[0]), dtype=torch.float64, device=sky.device)
+    out = torch.empty((nc, sky.shape[0]), dtype=data.dtype, device=sky.device)
+    lib = _lib.load()
+    fn = lib.pxl_sample_car_bilinear_f32 if data.dtype == torch.float32 else lib.pxl_sample_car_bilinear_f64
     with torch.cuda.device(sky.device):
-        _lib.check(_lib.load().pxl_sample_car_bilinear_f64(
+        _lib.check(fn(
             _wcs_ref(m.wcs), _lib.shape_arr((shape[0], shape[1], nc)), _ptr(data), row0, nrows, sky.shape[0],
             _ptr(sky), _ptr(out), _stream(sky)))
     return out

@@ -638,3 +638,72 @@ def test_reproject_random_geometries(pj, O, dev, seed):
             assert bits_equal(got, expect), (seed, case, variant, shape_in, wcs_in, shape_out, wcs_out,
                                              float(np.nanmax(np.abs(got - expect))))
             plan.close()
+
+
+# ---- Float32 maps (Enmap{Float32}): Float64 coordinates and weights, one rounding at the store --------
+
+def _f32_equal(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    return a.shape == b.shape and np.array_equal(a.view(np.int32), b.view(np.int32))
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_reproject_float32_vs_oracle(pj, O, dev, variant):
+    rng = np.random.default_rng(4242)
+    for name, ((shape_in, wcs_in), (shape_out, wcs_out)) in reproject_cases(pj).items():
+        nx, ny = shape_in[:2]
+        nc = 2
+        src = rng.normal(size=(nc, ny, nx)).astype(np.float32)
+        expect = O.reproject_f32(wcs_in, (nx, ny, nc), src, wcs_out, shape_out)
+        plan = pj.ReprojectPlan((nx, ny, nc), wcs_in, shape_out, wcs_out, device=dev)
+        plan.set_variant(variant)
+        dst = torch.full(plan.dst_tensor_shape(), float("nan"), dtype=torch.float32, device=dev)
+        plan.execute(torch.from_numpy(src).to(dev), dst)
+        got = dst.cpu().numpy()
+        assert np.isfinite(got).all(), name
+        assert _f32_equal(got, expect), (name, variant, float(np.abs(got - expect).max()))
+        plan.close()
+
+
+def test_reproject_float32_random_geometries(pj, O, dev):
+    rng = np.random.default_rng(5151)
+    for case in range(60):
+        shape_in, wcs_in = _random_geometry(pj, rng)
+        shape_out, wcs_out = _random_geometry(pj, rng)
+        if rng.random() < 0.5:
+            wcs_out = pj.CarClenshawCurtis(wcs_out.cdelt, wcs_out.crpix, (wcs_in.crval[0] + rng.uniform(-5, 5), 0.0))
+        src = rng.normal(size=(1, shape_in[1], shape_in[0])).astype(np.float32)
+        expect = O.reproject_f32(wcs_in, (shape_in[0], shape_in[1], 1), src, wcs_out, shape_out)
+        m = pj.Enmap(torch.from_numpy(src[0]).to(dev), wcs_in)
+        out = pj.reproject(m, shape_out, wcs_out)
+        assert out.data.dtype == torch.float32
+        assert _f32_equal(out.data.cpu().numpy()[None], expect), (case, shape_in, wcs_in, shape_out, wcs_out)
+
+
+def test_sample_float32_vs_oracle(pj, O, dev):
+    rng = np.random.default_rng(6161)
+    for name, (shape, wcs) in geoms(pj).items():
+        if shape[0] * shape[1] > 4_000_000:
+            continue
+        nx, ny = shape
+        src = rng.normal(size=(2, ny, nx)).astype(np.float32)
+        n = 12345
+        sky = np.stack([2 * math.pi * rng.random(n) - math.pi, np.arcsin(2 * rng.random(n) - 1)], axis=1)
+        m = pj.Enmap(torch.from_numpy(src).to(dev), wcs)
+        got = pj.sample_bilinear(m, to_dev(sky, dev))
+        assert got.dtype == torch.float32
+        assert _f32_equal(got.cpu().numpy(), O.sample_bilinear_f32(wcs, (nx, ny, 2), src, sky)), name
+
+
+def test_float32_and_float64_agree(pj, dev):
+    """The Float32 path is the Float64 path with storage rounding: results agree to Float32 precision."""
+    (shape_in, wcs_in), (shape_out, wcs_out) = reproject_cases(pj)["refine2x_to_1000"]
+    g = torch.Generator(device="cpu").manual_seed(5)
+    a = torch.randn((shape_in[1], shape_in[0]), dtype=torch.float32, generator=g).to(dev)
+    r32 = pj.reproject(pj.Enmap(a, wcs_in), shape_out, wcs_out).data
+    r64 = pj.reproject(pj.Enmap(a.double(), wcs_in), shape_out, wcs_out).data
+    assert torch.equal(r32, r64.float())
+    with pytest.raises(TypeError):
+        plan = pj.ReprojectPlan(shape_in, wcs_in, shape_out, wcs_out, device=dev)
+        plan.execute(a, torch.empty((shape_out[1], shape_out[0]), dtype=torch.float64, device=dev))

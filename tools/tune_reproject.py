@@ -27,15 +27,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="cfg4")
     ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("variants", nargs="+")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     shape_in, wcs_in, shape_out, wcs_out, desc = bench.workload_geometry(args.workload)
     nx, ny, nc = shape_in
     nxo, nyo = shape_out
-    src = torch.empty((nc, ny, nx), dtype=torch.float64, device=dev)
-    dst = torch.empty((nc, nyo, nxo), dtype=torch.float64, device=dev)
-    pj.fill_random_(src, 1234)
+    if args.dtype == "f32":
+        src = torch.randn((nc, ny, nx), dtype=torch.float32, device=dev)
+        dst = torch.empty((nc, nyo, nxo), dtype=torch.float32, device=dev)
+    else:
+        src = torch.empty((nc, ny, nx), dtype=torch.float64, device=dev)
+        dst = torch.empty((nc, nyo, nxo), dtype=torch.float64, device=dev)
+        pj.fill_random_(src, 1234)
     plans = []
     for v in args.variants:
         for k in KEYS.values():
@@ -58,7 +63,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             times[i].append(e0.elapsed_time(e1))
-    alg = 8.0 * nc * (nx * ny + nxo * nyo)
+    alg = (4.0 if args.dtype == "f32" else 8.0) * nc * (nx * ny + nxo * nyo)
     print("workload:", desc)
     for v, t in zip(args.variants, times):
         t = sorted(t)
