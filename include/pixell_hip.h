@@ -182,6 +182,8 @@ int pxl_sample_car_bilinear_f32(const pxl_car_wcs* wcs_in, const int64_t shape_i
  *      decode writes native Float64 (in place allowed for -64), encode writes big-endian Float64.          */
 int pxl_fits_decode_f64(const void* raw_be, double* dst, int64_t n, int bitpix, void* stream);
 int pxl_fits_encode_f64(const double* src, void* raw_be, int64_t n, void* stream);
+/* BITPIX -32 <-> native Float32 (the 4-byte swap is its own inverse; in place allowed) */
+int pxl_fits_swap_f32(const void* src, void* dst, int64_t n, void* stream);
 
 /* ---- synthetic inputs (benchmark plumbing, deterministic counter-based generator):
  *      fill n doubles with N(0,1) (kind 0) or U[0,1) (kind 1) from splitmix64(seed, index+offset);

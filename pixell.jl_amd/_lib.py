@@ -63,6 +63,7 @@ SIGNATURES = {
     "pxl_sample_car_bilinear_f32": (C.c_int, [_WP, _SHP, _P, _I64, _I64, _I64, _P, _P, _P]),
     "pxl_fits_decode_f64": (C.c_int, [_P, _P, _I64, C.c_int, _P]),
     "pxl_fits_encode_f64": (C.c_int, [_P, _P, _I64, _P]),
+    "pxl_fits_swap_f32": (C.c_int, [_P, _P, _I64, _P]),
     "pxl_fill_random_f64": (C.c_int, [_P, _I64, C.c_uint64, C.c_uint64, C.c_int, _P]),
     "pxl_fill_sphere_points_f64": (C.c_int, [_P, _I64, C.c_uint64, C.c_uint64, _P]),
 }

@@ -680,6 +680,14 @@ int pxl_fits_decode_f64(const void* raw_be, double* dst, int64_t n, int bitpix, 
     return check_launch("k_bswap_to_f64");
 }
 
+int pxl_fits_swap_f32(const void* src, void* dst, int64_t n, void* stream) {
+    if (n < 0 || (n > 0 && (!src || !dst))) return fail(PXL_EINVAL, "fits_swap_f32: null buffer or negative n");
+    if (n == 0) return PXL_OK;
+    hipLaunchKernelGGL(k_bswap32, dim3(stream_grid((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint32_t*)src, (uint32_t*)dst, n);
+    return check_launch("k_bswap32");
+}
+
 int pxl_fits_encode_f64(const double* src, void* raw_be, int64_t n, void* stream) {
     if (n < 0 || (n > 0 && (!raw_be || !src))) return fail(PXL_EINVAL, "fits_encode: null buffer or negative n");
     if (n == 0) return PXL_OK;

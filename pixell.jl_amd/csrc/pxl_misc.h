@@ -21,6 +21,17 @@ __global__ __launch_bounds__(256) void k_bswap_to_f64(const void* raw, double* d
         }
     }
 }
+// 4-byte elements: the swap is its own inverse (BITPIX -32 <-> native Float32, either direction)
+__global__ __launch_bounds__(256) void k_bswap32(const uint32_t* raw, uint32_t* dst, int64_t n) {
+    const int64_t chunk = (int64_t)blockDim.x * 4;
+    for (int64_t k0 = (int64_t)blockIdx.x * chunk + threadIdx.x; k0 < n; k0 += (int64_t)gridDim.x * chunk) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int64_t k = k0 + u * blockDim.x;
+            if (k < n) dst[k] = __builtin_bswap32(raw[k]);
+        }
+    }
+}
 __global__ __launch_bounds__(256) void k_f64_to_be(const double* __restrict__ src, uint64_t* __restrict__ raw, int64_t n) {
     const int64_t chunk = (int64_t)blockDim.x * 4;
     for (int64_t k0 = (int64_t)blockIdx.x * chunk + threadIdx.x; k0 < n; k0 += (int64_t)gridDim.x * chunk) {

@@ -77,9 +77,11 @@ def wcs_from_header(h):
                              (float(h.get("CRVAL1", 0.0)), float(h.get("CRVAL2", 0.0))), unit)
 
 
-def read_map(path, device="cuda", sel=None, verbose=False):
+def read_map(path, device="cuda", sel=None, verbose=False, dtype=None):
     """read_map(path; sel) -> Enmap on the device.  sel = (sel_x, sel_y[, sel_c]) with the 1-based inclusive
-    selections of geometry.slice_geometry (e.g. ((11, 20), (21, 40), (1, 2)) for 11:20, 21:40, 1:2)."""
+    selections of geometry.slice_geometry (e.g. ((11, 20), (21, 40), (1, 2)) for 11:20, 21:40, 1:2).
+    The element type follows the file (BITPIX -64 -> Float64, -32 -> Float32, like the reference's read);
+    dtype=torch.float64 widens a Float32 file on the device."""
     h, offset = read_header(path)
     bitpix = h["BITPIX"]
     if bitpix not in (-64, -32):
@@ -92,10 +94,16 @@ def read_map(path, device="cuda", sel=None, verbose=False):
     raw = np.memmap(path, dtype=np.uint8, mode="r", offset=offset, shape=(n * (-bitpix // 8),))
     dev = torch.device(device)
     d_raw = torch.from_numpy(np.array(raw)).to(dev)            # one host copy of the data block, then H2D
-    out = torch.empty(tuple(reversed(dims)), dtype=torch.float64, device=dev)
+    want = dtype if dtype is not None else (torch.float64 if bitpix == -64 else torch.float32)
+    out = torch.empty(tuple(reversed(dims)), dtype=want, device=dev)
     with torch.cuda.device(dev):
         s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(_lib.load().pxl_fits_decode_f64(C.c_void_p(d_raw.data_ptr()), C.c_void_p(out.data_ptr()), n, bitpix, s))
+        if want == torch.float32:
+            if bitpix != -32:
+                raise ValueError("a BITPIX -64 file cannot be read as Float32 without loss; read it as Float64")
+            _lib.check(_lib.load().pxl_fits_swap_f32(C.c_void_p(d_raw.data_ptr()), C.c_void_p(out.data_ptr()), n, s))
+        else:
+            _lib.check(_lib.load().pxl_fits_decode_f64(C.c_void_p(d_raw.data_ptr()), C.c_void_p(out.data_ptr()), n, bitpix, s))
     wcs = wcs_from_header(h)
     # IAU <-> COSMO (enmap.jl:178-195,206-211): flip U (third Stokes plane) when the file says POLCCONV = IAU
     if "STOKES" in [v for v in h.values() if isinstance(v, str)] and h.get("POLCCONV", "COSMO") == "IAU" and naxis == 3:
@@ -128,11 +136,13 @@ def _card(key, value, comment=""):
 def write_map(path, m: Enmap):
     """write_map(fname, emap) -- enmap.jl:225-237: BITPIX -64 primary HDU + the CAR WCS cards, degrees."""
     data = m.data
-    if data.dtype != torch.float64 or not data.is_contiguous():
-        raise TypeError("write_map needs a contiguous float64 map")
+    if data.dtype not in (torch.float64, torch.float32) or not data.is_contiguous():
+        raise TypeError("write_map needs a contiguous float64 or float32 map")
+    f32 = data.dtype == torch.float32
     shape = m.shape
     wcs = m.wcs
-    cards = [_card("SIMPLE", True, "file does conform to FITS standard"), _card("BITPIX", -64, "number of bits per data pixel"),
+    cards = [_card("SIMPLE", True, "file does conform to FITS standard"),
+             _card("BITPIX", -32 if f32 else -64, "number of bits per data pixel"),
              _card("NAXIS", len(shape), "number of data axes")]
     for k, nk in enumerate(shape):
         cards.append(_card("NAXIS%d" % (k + 1), int(nk), "length of data axis %d" % (k + 1)))
@@ -145,10 +155,13 @@ def write_map(path, m: Enmap):
     header = "".join(cards)
     header += " " * (-len(header) % BLOCK)
     n = data.numel()
-    raw = torch.empty(n, dtype=torch.int64, device=data.device)
+    raw = torch.empty(n, dtype=torch.int32 if f32 else torch.int64, device=data.device)
     with torch.cuda.device(data.device):
         s = C.c_void_p(torch.cuda.current_stream(data.device).cuda_stream)
-        _lib.check(_lib.load().pxl_fits_encode_f64(C.c_void_p(data.data_ptr()), C.c_void_p(raw.data_ptr()), n, s))
+        if f32:
+            _lib.check(_lib.load().pxl_fits_swap_f32(C.c_void_p(data.data_ptr()), C.c_void_p(raw.data_ptr()), n, s))
+        else:
+            _lib.check(_lib.load().pxl_fits_encode_f64(C.c_void_p(data.data_ptr()), C.c_void_p(raw.data_ptr()), n, s))
     payload = raw.cpu().numpy().tobytes()
     with open(path, "wb") as f:
         f.write(header.encode("ascii"))

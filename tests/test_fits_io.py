@@ -58,3 +58,23 @@ def test_write_read_roundtrip(pj, tmp_path):
     assert back.wcs.crpix == wcs.crpix and back.wcs.crval == wcs.crval and back.wcs.cdelt == wcs.cdelt
     h, _ = pj.read_header(path)
     assert h["CTYPE1"] == "RA---CAR" and h["CUNIT1"] == "deg" and h["NAXIS3"] == 3
+
+
+@pytest.mark.gpu
+def test_float32_files_roundtrip(pj, tmp_path):
+    """BITPIX -32 files stay Float32 on the device (as the reference's read keeps the file's element type) and
+    can be widened on request; a Float32 map written and read back is unchanged."""
+    import math
+    import torch
+    shape, wcs = pj.fullsky_geometry(2 * math.pi / 64, dims=(2,))
+    m = pj.Enmap(torch.randn((2, shape[1], shape[0]), dtype=torch.float32, device="cuda:0"), wcs)
+    path = str(tmp_path / "f32.fits")
+    pj.write_map(path, m)
+    h, off = pj.read_header(path)
+    assert h["BITPIX"] == -32 and os.path.getsize(path) % 2880 == 0
+    host = np.frombuffer(open(path, "rb").read()[off:off + m.data.numel() * 4], dtype=">f4").astype("<f4")
+    assert np.array_equal(host.reshape(m.data.shape), m.data.cpu().numpy())
+    back = pj.read_map(path, device="cuda:0")
+    assert back.data.dtype == torch.float32 and torch.equal(back.data, m.data) and back.wcs.crpix == wcs.crpix
+    wide = pj.read_map(path, device="cuda:0", dtype=torch.float64)
+    assert wide.data.dtype == torch.float64 and torch.equal(wide.data, m.data.double())
