@@ -106,3 +106,46 @@ def test_error_codes(env):
     # empty work is a successful no-op
     assert lib.pxl_pix2sky_car_f64(C.byref(w), 0, None, None, 0, None) == 0
     assert lib.pxl_sample_car_bilinear_f64(C.byref(w), pj._lib.shape_arr((360, 181, 1)), None, 0, 0, 0, None, None, None) == 0
+
+
+def test_concurrent_host_threads_and_streams(env, O):
+    """The boundary claims thread safety (thread-local error text, no shared mutable state): four host threads,
+    each with its own stream, plan and buffers, reproject different geometries at the same time."""
+    import threading
+    pj, lib, dev = env
+    cases = []
+    rng = np.random.default_rng(9)
+    for n_in, n_out in ((96, 192), (200, 150), (128, 128), (90, 360)):
+        shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / n_in)
+        shape_out, wcs_out = pj.fullsky_geometry(2 * math.pi / n_out)
+        src = rng.normal(size=(1, shape_in[1], shape_in[0]))
+        cases.append((shape_in, wcs_in, shape_out, wcs_out, src, O.reproject(wcs_in, shape_in, src, wcs_out, shape_out)))
+    results, errors = [None] * len(cases), []
+
+    def work(k):
+        try:
+            shape_in, wcs_in, shape_out, wcs_out, src, _ = cases[k]
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                d_src = torch.from_numpy(src).to(dev, non_blocking=False)
+                for _ in range(20):                       # plan churn + execution on this thread's stream
+                    plan = pj.ReprojectPlan(shape_in, wcs_in, shape_out, wcs_out, device=dev)
+                    dst = torch.empty(plan.dst_tensor_shape(), dtype=torch.float64, device=dev)
+                    plan.execute(d_src, dst)
+                    st.synchronize()
+                    plan.close()
+                results[k] = dst.cpu().numpy()
+            # a failing call on this thread leaves ITS message, not another thread's
+            rc = lib.pxl_pix2sky_car_f64(None, 0, None, None, 0, None)
+            assert rc == -22 and "WCS" in pj._lib.last_error()
+        except Exception as e:                            # pragma: no cover
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(cases))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k, case in enumerate(cases):
+        assert bits_equal(results[k], case[5]), k
