@@ -131,7 +131,10 @@ int pxl_reproject_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[
 /* enqueue table build + reprojection of all nc components on `stream` */
 int pxl_reproject_execute(pxl_reproject_plan* plan, const double* src, double* dst, void* stream);
 /* as above but only output rows [r0, r0+nr) RELATIVE to the plan's dst window (for interior/boundary
- * splitting while a halo is in flight); tables must have been built by a previous execute/build.    */
+ * splitting while a halo is in flight); the tables must have been built by a previous execute/build ON THE
+ * SAME STREAM (or one the caller has ordered before this one).  A plan may be shared by host threads only
+ * for concurrent execute_rows calls; create/build/destroy are the owner's.  src and dst must not overlap.
+ * Tuning knobs read once at plan creation: PXL_REPROJECT_{RH,PAIRS,NS,PF,VARIANT,FLAGS}.   */
 int pxl_reproject_build_tables(pxl_reproject_plan* plan, void* stream);
 int pxl_reproject_execute_rows(pxl_reproject_plan* plan, const double* src, double* dst,
                                int64_t r0, int64_t nr, void* stream);
