@@ -1,0 +1,58 @@
+# test_pixellhip.jl -- the reference's own known answers, through the ccall binding (julia/PixellHIP.jl).
+# NOT RUN IN THIS REPOSITORY'S CI (no Julia in the build image); kept ready for a box that has
+# Julia >= 1.6, Pixell.jl and an MI355X:
+#     PIXELL_HIP_LIB=/path/to/libpixell_hip.so julia --project test_pixellhip.jl
+# The literals are those of /root/reference/test/test_geometry.jl (cited per test).
+using Test
+using Pixell
+include("PixellHIP.jl")
+using .PixellHIP
+
+@testset "device pix2sky / sky2pix vs the reference CPU path (bit for bit)" begin
+    shape, wcs = fullsky_geometry(deg2rad(1))                         # test_geometry.jl:50
+    pix = 400 .* rand(2, 100_000) .- 20
+    dpix = HIPArray(pix)
+    # safe=false: affine only (test_geometry.jl:67-72 compares this path with wcslib)
+    @test Array(pix2sky(shape, wcs, dpix; safe=false)) == pix2sky(shape, wcs, pix; safe=false)
+    # safe=true: rewind + DSP.unwrap along the point axis (car_proj.jl:110-112)
+    @test Array(pix2sky(shape, wcs, dpix; safe=true)) == pix2sky(shape, wcs, pix; safe=true)
+    sky = pix2sky(shape, wcs, pix; safe=false)
+    dsky = HIPArray(sky)
+    for safe in (true, false)
+        @test Array(sky2pix(shape, wcs, dsky; safe=safe)) == sky2pix(shape, wcs, sky; safe=safe)
+    end
+end
+
+@testset "known answers (test_geometry.jl:52-64)" begin
+    shape, wcs = fullsky_geometry(deg2rad(1))
+    pix = [2.0 11.0 41.0; 2.0 -12.0 -29.0]
+    sky = Array(pix2sky(shape, wcs, HIPArray(pix); safe=true))
+    @test sky[:, 1] ≈ [3.12413936, -1.55334303]
+    @test sky[:, 2] ≈ [2.96705973, -1.79768913]
+    @test sky[:, 3] ≈ [2.44346095, -2.0943951]
+    back = Array(sky2pix(shape, wcs, HIPArray(sky .+ [12π, 16π]); safe=true))      # 2*pi*k invariance, :63-64
+    @test back[:, 1] ≈ [2.0, 2.0]
+end
+
+@testset "posmap (enmap_ops.jl:190-203) and range invariants (test_geometry.jl:207-223)" begin
+    shape, wcs = fullsky_geometry(deg2rad(1))
+    ra, dec = PixellHIP.posmap_device(shape, wcs)
+    ra0, dec0 = posmap(shape, wcs)
+    @test Array(parent(ra)) == parent(ra0)
+    @test Array(parent(dec)) == parent(dec0)
+    @test all(-π .≤ Array(parent(ra)) .≤ π) && all(-π / 2 .≤ Array(parent(dec)) .≤ π / 2)
+end
+
+@testset "reproject: identity, partition of unity, half-pixel shift across the RA seam" begin
+    shape, wcs = fullsky_geometry(2π / 256)
+    m = Enmap(HIPArray(randn(shape...)), wcs)
+    same = PixellHIP.reproject(m, shape, wcs)
+    @test maximum(abs.(Array(parent(same)) .- Array(parent(m)))) < 1e-12
+    ones_map = Enmap(HIPArray(ones(shape...)), wcs)
+    shape2, wcs2 = fullsky_geometry(2π / 512)
+    @test maximum(abs.(Array(parent(PixellHIP.reproject(ones_map, shape2, wcs2))) .- 1)) < 1e-13
+    shifted = CarClenshawCurtis{Float64}(wcs.cdelt, wcs.crpix .- (0.5, 0.0), wcs.crval, wcs.unit)
+    out = Array(parent(PixellHIP.reproject(m, shape, shifted)))
+    src = Array(parent(m))
+    @test maximum(abs.(out .- 0.5 .* (src .+ circshift(src, (-1, 0))))) < 1e-12
+end
