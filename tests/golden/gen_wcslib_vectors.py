@@ -56,6 +56,18 @@ def main():
                                  world_deg=hexs(sky2_deg), world2pix=hexs(pix2),
                                  pix_small=hexs(pix_small), pix2world_small_deg=hexs(sky_small_deg),
                                  world_small_deg=hexs(world_small_deg), world2pix_small=hexs(pix_from_small)))
+    # Gnomonic: the reference pins its TAN evaluators against wcslib too (test_geometry.jl:92-119: scalars with
+    # `≈`, and the L1 difference of a full 1827x1825 posmap below 1e-9)
+    tan = dict(shape=[1827, 1825], cdelt=[0.008333333333333333, 0.008333333333333333],
+               crpix=[913.3649509696, 921.0316523678962], crval=[97.50416559979826, -7.45833685170031])
+    T = awcs.WCS(naxis=2)
+    T.wcs.ctype = ["RA---TAN", "DEC--TAN"]
+    T.wcs.cdelt = tan["cdelt"]; T.wcs.crpix = tan["crpix"]; T.wcs.crval = tan["crval"]
+    tpix = np.stack([1 + 1826 * rng.random(2048), 1 + 1824 * rng.random(2048)], axis=1)
+    tsky = T.wcs_pix2world(tpix, 1)
+    tback = T.wcs_world2pix(tsky, 1)
+    assert np.all(np.isfinite(tsky)) and np.max(np.abs(tback - tpix)) < 1e-6
+    out["tan"] = dict(geom=tan, pix=hexs(tpix), pix2world_deg=hexs(tsky))
     with open(os.path.join(HERE, "wcslib_car_vectors.json"), "w") as f:
         json.dump(out, f)
     print("wrote", len(out["cases"]), "cases")

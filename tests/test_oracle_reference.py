@@ -341,3 +341,19 @@ def test_oracle_reproduces_its_frozen_outputs(O):
     assert bits_equal(O.pix2sky(w, pix, O.WRAP_UNWIND), unhex(g["pix2sky_unwind"]))
     sky = unhex(g["pix2sky_unsafe"])
     assert bits_equal(O.sky2pix(w, shape, sky, safe=True, form=O.FORM_RECIP), unhex(g["sky2pix_safe_recip"]))
+
+
+def test_gnomonic_against_wcslib_tan(O, wcslib_vectors):
+    """test_geometry.jl:92-119 pins the Gnomonic evaluators against wcslib's TAN; so do we (wcslib 7.6 vectors)."""
+    t = wcslib_vectors["tan"]
+    g = t["geom"]
+
+    class W:
+        cdelt, crpix, crval, unit = g["cdelt"], g["crpix"], g["crval"], DEG
+    pix = unhex(t["pix"])
+    ref = unhex(t["pix2world_deg"]) * DEG
+    ra, dec = O.pix2sky_tan(W, pix[:, 0], pix[:, 1])
+    dra = np.abs((ra - ref[:, 0] + math.pi) % (2 * math.pi) - math.pi)          # wcslib reports RA in [0, 360)
+    assert np.max(dra) < 1e-11 and np.max(np.abs(dec - ref[:, 1])) < 1e-11
+    x, y = O.sky2pix_tan(W, ref[:, 0], ref[:, 1])
+    assert np.max(np.abs(x - pix[:, 0])) < 1e-7 and np.max(np.abs(y - pix[:, 1])) < 1e-7
