@@ -68,6 +68,32 @@ def main():
     tback = T.wcs_world2pix(tsky, 1)
     assert np.all(np.isfinite(tsky)) and np.max(np.abs(tback - tpix)) < 1e-6
     out["tan"] = dict(geom=tan, pix=hexs(tpix), pix2world_deg=hexs(tsky))
+    # An independent end-to-end reprojection: wcslib for both coordinate steps + scipy order-1 interpolation
+    # (python-pixell's `project(..., order=1)` pipeline, which Pixell.jl says it mirrors): a 64x33 full-sky CC map
+    # with analytic content onto a half-pixel-shifted 96x49 grid.
+    from scipy.ndimage import map_coordinates
+    def cc(nx):
+        ny = nx // 2 + 1
+        W = awcs.WCS(naxis=2)
+        W.wcs.ctype = ["RA---CAR", "DEC--CAR"]
+        W.wcs.cdelt = [-360.0 / nx, 180.0 / (ny - 1)]
+        W.wcs.crpix = [nx // 2 + 0.5, (ny + 1) / 2]
+        W.wcs.crval = [(np.pi / (ny - 1)) * 90 / np.pi, 0.0]
+        return W, nx, ny
+    Win, nxi, nyi = cc(64)
+    Wout, nxo, nyo = cc(96)
+    Wout.wcs.crpix = [Wout.wcs.crpix[0] + 0.37, Wout.wcs.crpix[1]]
+    jj, ii = np.meshgrid(np.arange(1, nyi + 1, dtype=float), np.arange(1, nxi + 1, dtype=float), indexing="ij")
+    src = np.sin(0.2 * ii) * np.cos(0.3 * jj) + 0.01 * ii
+    oj, oi = np.meshgrid(np.arange(2, nyo, dtype=float), np.arange(1, nxo + 1, dtype=float), indexing="ij")  # skip pole rows
+    world = Wout.wcs_pix2world(np.stack([oi.ravel(), oj.ravel()], axis=1), 1)
+    pin = Win.wcs_world2pix(world, 1)
+    assert np.all(np.isfinite(pin))
+    ref = map_coordinates(src, [pin[:, 1] - 1, pin[:, 0] - 1], order=1, mode="grid-wrap")
+    out["reproject_wcslib_scipy"] = dict(
+        geom_in=dict(shape=[nxi, nyi], cdelt=list(Win.wcs.cdelt), crpix=list(Win.wcs.crpix), crval=list(Win.wcs.crval)),
+        geom_out=dict(shape=[nxo, nyo], cdelt=list(Wout.wcs.cdelt), crpix=list(Wout.wcs.crpix), crval=list(Wout.wcs.crval)),
+        src=hexs(src), rows=[2, nyo - 1], expected=hexs(ref))
     with open(os.path.join(HERE, "wcslib_car_vectors.json"), "w") as f:
         json.dump(out, f)
     print("wrote", len(out["cases"]), "cases")
