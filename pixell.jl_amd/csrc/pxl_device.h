@@ -14,19 +14,56 @@
 
 namespace pxl {
 
+// Exact C fmod(x, y) for y > 0 without the library's bit-serial reduction loop (~100 instructions per call).
+// With q an integer within one of trunc(|x|/y), v = |x| - q*y is an integer multiple of ulp(y) below 2y in
+// magnitude, and fma evaluates it with a single rounding: whenever the result lands in [0, y) it IS v (every
+// multiple of ulp(y) in that range is representable), i.e. the true remainder; otherwise its sign / size says
+// which neighbour of q is the quotient, and the fma is redone with it.  The fma here is exact-arithmetic
+// machinery, not contraction: the value returned is fmod's, bit for bit (sign of x, also on zero).  Huge
+// quotients, NaN/Inf and extreme periods take the library fmod.  ry ~ 1/y (any few-ulp approximation).
+// Branch-free attempt: *ok says whether the value returned is fmod(x, y) (it is not for NaN/Inf, quotients
+// beyond 2^50 and extreme periods -- the caller then takes the library fmod).
+__host__ __device__ inline double fmod_pos_try(double x, double y, double ry, bool* ok) {
+    const double ax = fabs(x);
+    double q = trunc(ax * ry);
+    double r = __builtin_fma(-q, y, ax);
+    q = r < 0.0 ? q - 1.0 : (r >= y ? q + 1.0 : q);
+    r = __builtin_fma(-q, y, ax);                                   // exact once q is the true quotient
+    *ok = ax < y * 0x1p50 && r >= 0.0 && r < y && y >= 0x1p-900 && y <= 0x1p900;
+    return copysign(r, x);
+}
+__host__ __device__ inline double fmod_pos(double x, double y, double ry) {
+    bool ok;
+    const double r = fmod_pos_try(x, y, ry, &ok);
+    if (__builtin_expect(ok, 1)) return r;
+    return fmod(x, y);
+}
+
 // Julia Base.mod(x::Float64, y::Float64): r = rem(x, y); r == 0 -> copysign(r, y);
 // (r > 0) xor (y > 0) -> r + y; else r.   fmod is exact, so this is bit-identical on any IEEE target.
-__host__ __device__ inline double jl_mod(double x, double y) {
-    double r = fmod(x, y);
+__host__ __device__ inline double jl_mod(double x, double y, double ry) {
+    double r = (y > 0.0) ? fmod_pos(x, y, ry) : fmod(x, y);
     if (r == 0.0) return copysign(r, y);
     if ((r > 0.0) != (y > 0.0)) return r + y;
     return r;
 }
+__host__ __device__ inline double jl_mod(double x, double y) { return jl_mod(x, y, 1.0 / y); }
 
 // rewind, enmap_ops.jl:10-13: ref + mod(a - ref + period/2, period) - period/2, left to right.
-__host__ __device__ inline double rewind(double a, double period, double ref) {
+// rperiod ~ 1/period only seeds the quotient guess of fmod_pos; it does not enter the result.
+__host__ __device__ inline double rewind(double a, double period, double ref, double rperiod) {
     double half = period / 2;
-    return (ref + jl_mod((a - ref) + half, period)) - half;
+    return (ref + jl_mod((a - ref) + half, period, rperiod)) - half;
+}
+__host__ __device__ inline double rewind(double a, double period, double ref) {
+    return rewind(a, period, ref, 1.0 / period);
+}
+// The same for period > 0 without a branch; *ok false -> the caller must use rewind() instead.
+__host__ __device__ inline double rewind_try(double a, double period, double ref, double rperiod, bool* ok) {
+    const double half = period / 2;
+    const double r = fmod_pos_try((a - ref) + half, period, rperiod, ok);
+    const double mod = r == 0.0 ? 0.0 : (r < 0.0 ? r + period : r);   // jl_mod for y > 0
+    return (ref + mod) - half;
 }
 
 // Pre-multiplied WCS scalars: the prologues of car_proj.jl:95-98 and :168-173.
@@ -53,6 +90,7 @@ struct Sky2Pix {
     double rda, rdd;   // 1/da, 1/dd            car_proj.jl:173
     double cx, cy;     // shape[1:2] ./ 2 .+ 1   car_proj.jl:186
     double px, py;     // pixel periods          car_proj.jl:187 / :229-230 / :247-248
+    double rpx, rpy;   // ~1/px, ~1/py: quotient seeds for fmod_pos only
     int form, safe;
 };
 __host__ __device__ inline Sky2Pix sky2pix_setup(const pxl_car_wcs& w, int64_t nx, int64_t ny, int safe, int form) {
@@ -62,16 +100,17 @@ __host__ __device__ inline Sky2Pix sky2pix_setup(const pxl_car_wcs& w, int64_t n
     s.cx = (double)nx / 2 + 1; s.cy = (double)ny / 2 + 1;
     if (form == PXL_FORM_RECIP_AV) { s.px = fabs(PXL_TWOPI_D * s.rda); s.py = fabs(PXL_TWOPI_D * s.rdd); }
     else                           { s.px = fabs(PXL_TWOPI_D / s.c.da); s.py = fabs(PXL_TWOPI_D / s.c.dd); }
+    s.rpx = 1.0 / s.px; s.rpy = 1.0 / s.py;
     s.form = form; s.safe = safe;
     return s;
 }
 __host__ __device__ inline double s2p_x(const Sky2Pix& s, double a) {
     double ix = (s.form == PXL_FORM_DIV) ? s.c.ia0 + (a - s.c.a0) / s.c.da : s.c.ia0 + (a - s.c.a0) * s.rda;
-    return s.safe ? rewind(ix, s.px, s.cx) : ix;
+    return s.safe ? rewind(ix, s.px, s.cx, s.rpx) : ix;
 }
 __host__ __device__ inline double s2p_y(const Sky2Pix& s, double d) {
     double iy = (s.form == PXL_FORM_DIV) ? s.c.id0 + (d - s.c.d0) / s.c.dd : s.c.id0 + (d - s.c.d0) * s.rdd;
-    return s.safe ? rewind(iy, s.py, s.cy) : iy;
+    return s.safe ? rewind(iy, s.py, s.cy, s.rpy) : iy;
 }
 
 // Split a 1-based Float64 pixel coordinate into integer cell + fraction.  The cell index is clamped to

@@ -8,7 +8,8 @@
 // per lane are in flight (a single dependent load/store per trip left the stream at 57 % of HBM peak).
 #define PXL_UNR 4
 __global__ __launch_bounds__(256) void k_pix2sky_pairs(CarAffine c, int64_t n, const double2* pix,
-                                                       double2* sky, int mode) {
+                                                       double2* sky, int mode, const int32_t* gate) {
+    if (gate && *gate == 0) return;      // fallback launches of the unwind path: run only when the fused form failed
     // mode 0: affine only; 1: rewind; 2: rewind and leave m = rewound - ref for the unwrap passes (ref = 0)
     // a block sweeps contiguous chunks of 256*UNR points (like a copy kernel): the UNR requests of a lane
     // are 4 KiB apart, not a power-of-two number of MiB apart (which camps on one HBM channel)

@@ -112,49 +112,105 @@ struct pxl_reproject_plan {
     bool tables_built;
 };
 
-// unwind!(sky2xN; dims=2) on a buffer that already holds m = rewind(.) - ref (see k_unwrap_* above).
-// Scratch comes from the stream-ordered allocator (hipMallocAsync / hipFreeAsync): no host synchronisation.
-static int unwind_rows(int64_t n, int nrow, double* sky, double period, double ref, hipStream_t st) {
-    if (n <= 4096) {       // tiny batches: the exact serial kernel is already fast enough
-        hipLaunchKernelGGL(k_unwind_rows, dim3(nrow), dim3(64), 0, st, n, nrow, sky, period, ref, 1, (const int32_t*)nullptr);
-        return check_launch("k_unwind_rows");
+// Scratch of one unwind! call, from the stream-ordered allocator (hipMallocAsync / hipFreeAsync): no host
+// synchronisation.  The multi-pass fallback needs per-element scratch (5 B per value); the fused path only
+// per-chunk entries.
+struct UnwindWs {
+    char* base;
+    int8_t* c; int32_t* rloc; int32_t* bsum; int32_t* boff;     // multi-pass form
+    int32_t* flag;                                              // [0],[1]: multi-pass verification; [2]: fused path failed
+    unsigned long long* firstnan;                               // first NaN of each coordinate row
+    int2* wsum; double2* wprev;                                 // fused form: per wave chunk
+    int64_t nb, nw;
+    int U;
+};
+
+static int unwind_ws_alloc(int64_t n, int nrow, hipStream_t st, UnwindWs* w) {
+    w->nb = (n + PXL_SCAN_BLOCK - 1) / PXL_SCAN_BLOCK;
+    // wave chunks of 64*U points: long enough to amortise the per-chunk work, short enough to fill the GPU
+    int64_t U = n / (64 * 4096);
+    U = U < 4 ? 4 : (U > 32 ? 32 : U);
+    U &= ~(int64_t)(PXL_UW_G - 1);
+    w->U = (int)U;
+    w->nw = (n + 64 * U - 1) / (64 * U);
+    if (w->nb > 0x7fffffffLL || w->nw > 0x7fffffffLL || n > 0x7fffffffLL) return fail(PXL_EINVAL, "unwind: batch too long (2^31 points)");
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t bytes_c = up((size_t)nrow * n), bytes_r = up((size_t)4 * nrow * n), bytes_b = up((size_t)4 * nrow * w->nb);
+    const size_t bytes_ws = up((size_t)w->nw * sizeof(int2)), bytes_wp = up((size_t)w->nw * sizeof(double2));
+    const size_t total = bytes_c + bytes_r + 2 * bytes_b + bytes_ws + bytes_wp + 256;
+    w->base = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&w->base, total, st));
+    char* p = w->base;
+    w->c = (int8_t*)p; p += bytes_c;
+    w->rloc = (int32_t*)p; p += bytes_r;
+    w->bsum = (int32_t*)p; p += bytes_b;
+    w->boff = (int32_t*)p; p += bytes_b;
+    w->wsum = (int2*)p; p += bytes_ws;
+    w->wprev = (double2*)p; p += bytes_wp;
+    w->flag = (int32_t*)p;
+    w->firstnan = (unsigned long long*)(p + 16);
+    if (hipMemsetAsync(w->flag, 0, 16, st) != hipSuccess || hipMemsetAsync(w->firstnan, 0xFF, 16, st) != hipSuccess) {
+        (void)hipFreeAsync(w->base, st);
+        return fail(PXL_EHIP, "unwind: hipMemsetAsync failed");
     }
-    const int64_t nb = (n + PXL_SCAN_BLOCK - 1) / PXL_SCAN_BLOCK;
-    if (nb > 0x7fffffffLL) return fail(PXL_EINVAL, "unwind: batch too long");
-    const size_t bytes_c = (size_t)nrow * n, bytes_r = (size_t)4 * nrow * n, bytes_b = (size_t)4 * nrow * nb;
-    const size_t off_r = (bytes_c + 255) & ~(size_t)255;
-    const size_t off_bs = off_r + ((bytes_r + 255) & ~(size_t)255);
-    const size_t off_bo = off_bs + ((bytes_b + 255) & ~(size_t)255);
-    const size_t off_fl = off_bo + ((bytes_b + 255) & ~(size_t)255);
-    char* ws = nullptr;
-    HIP_TRY(hipMallocAsync((void**)&ws, off_fl + 256, st));
-    int8_t* c = (int8_t*)ws;
-    int32_t* rloc = (int32_t*)(ws + off_r);
-    int32_t* bsum = (int32_t*)(ws + off_bs);
-    int32_t* boff = (int32_t*)(ws + off_bo);
-    int32_t* flag = (int32_t*)(ws + off_fl);
-    int rc = PXL_OK;
-    const unsigned g = stream_grid(n, 256);
-    hipLaunchKernelGGL(k_unwrap_incr, dim3(g), dim3(256), 0, st, n, nrow, (const double*)sky, period, c);
-    if (hipMemsetAsync(flag, 0, 2 * sizeof(int32_t), st) != hipSuccess) rc = fail(PXL_EHIP, "unwind: hipMemsetAsync failed");
-    for (int pass = 0; pass < 2 && rc == PXL_OK; ++pass) {
-        const int32_t* gate = pass == 0 ? nullptr : flag;        // pass 2 runs on the device only if pass 1 flagged
-        hipLaunchKernelGGL((k_scan_local<int8_t>), dim3((unsigned)nb, nrow), dim3(256), 0, st, n, (const int8_t*)c, rloc, bsum, nb, gate);
-        hipLaunchKernelGGL(k_scan_bsums, dim3(nrow), dim3(1024), 0, st, nb, (const int32_t*)bsum, boff, gate);
-        hipLaunchKernelGGL(k_unwrap_verify, dim3(g), dim3(256), 0, st, n, nrow, (const double*)sky, period, c,
-                           (const int32_t*)rloc, (const int32_t*)boff, nb, flag + pass, gate);
-        rc = check_launch("k_unwrap scan/verify");
-    }
-    if (rc == PXL_OK) {
-        hipLaunchKernelGGL(k_unwrap_apply, dim3(g), dim3(256), 0, st, n, nrow, sky, period, ref, (const int32_t*)rloc,
-                           (const int32_t*)boff, nb, (const int32_t*)flag);
-        hipLaunchKernelGGL(k_unwind_rows, dim3(nrow), dim3(64), 0, st, n, nrow, sky, period, ref, 1, (const int32_t*)flag);
-        rc = check_launch("k_unwrap_apply");
-    }
-    hipError_t e = hipFreeAsync(ws, st);
+    return PXL_OK;
+}
+
+static int unwind_ws_free(UnwindWs* w, hipStream_t st, int rc) {
+    hipError_t e = hipFreeAsync(w->base, st);
     if (e != hipSuccess && rc == PXL_OK) rc = fail(PXL_EHIP, "unwind: hipFreeAsync: %s", hipGetErrorString(e));
     return rc;
 }
+
+// Fused form (pxl_unwrap.h): sums -> scan -> verify + write.  `inplace`: out aliases the input, so verify without
+// storing first and store in a second launch that the device skips if the verification failed.
+template <class SRC>
+static int unwind_fused(const SRC& src, typename SRC::raw_t* out, int64_t n, bool inplace, UnwindWs& w, hipStream_t st) {
+    const dim3 grid((unsigned)w.nw), block(64);
+    int32_t* fastflag = w.flag + 2;
+    hipLaunchKernelGGL((k_unwind_sums<SRC>), grid, block, 0, st, src, n, w.U, w.wsum, w.wprev, w.firstnan);
+    hipLaunchKernelGGL(k_scan_wsums, dim3(1), dim3(1024), 0, st, w.nw, w.wsum);
+    if (inplace) {
+        hipLaunchKernelGGL((k_unwind_apply<SRC, false>), grid, block, 0, st, src, out, n, w.U, (const int2*)w.wsum,
+                           (const double2*)w.wprev, (const unsigned long long*)w.firstnan, fastflag, (const int32_t*)nullptr);
+        hipLaunchKernelGGL((k_unwind_apply<SRC, true>), grid, block, 0, st, src, out, n, w.U, (const int2*)w.wsum,
+                           (const double2*)w.wprev, (const unsigned long long*)w.firstnan, fastflag, (const int32_t*)fastflag);
+    } else {
+        hipLaunchKernelGGL((k_unwind_apply<SRC, true>), grid, block, 0, st, src, out, n, w.U, (const int2*)w.wsum,
+                           (const double2*)w.wprev, (const unsigned long long*)w.firstnan, fastflag, (const int32_t*)nullptr);
+    }
+    return check_launch("k_unwind fused");
+}
+
+// Multi-pass form on a buffer that already holds m = rewind(.) - ref (see k_unwrap_* in pxl_unwrap.h).  With
+// `gate` every launch is skipped on the device unless *gate != 0 (the fused form failed its verification).
+static int unwind_multipass(int64_t n, int nrow, double* sky, double period, double ref, UnwindWs& w, const int32_t* gate,
+                            hipStream_t st) {
+    int rc = PXL_OK;
+    // as a fallback these launches almost always exit at the gate: a small grid keeps that to a few microseconds each
+    // (390k empty blocks cost ~85 us per launch), and the kernels grid-stride when they do run
+    const unsigned cap = gate ? 2048u : 0xffffffffu;
+    const unsigned g = std::min(stream_grid(n, 256), cap);
+    const int64_t nb = w.nb;
+    hipLaunchKernelGGL(k_unwrap_incr, dim3(g), dim3(256), 0, st, n, nrow, (const double*)sky, period, w.c, gate);
+    for (int pass = 0; pass < 2 && rc == PXL_OK; ++pass) {
+        const int32_t* pg = pass == 0 ? gate : w.flag;          // pass 2 runs on the device only if pass 1 flagged
+        hipLaunchKernelGGL((k_scan_local<int8_t>), dim3(std::min((unsigned)nb, cap), nrow), dim3(256), 0, st, n, (const int8_t*)w.c, w.rloc, w.bsum, nb, pg);
+        hipLaunchKernelGGL(k_scan_bsums, dim3(nrow), dim3(1024), 0, st, nb, (const int32_t*)w.bsum, w.boff, pg);
+        hipLaunchKernelGGL(k_unwrap_verify, dim3(g), dim3(256), 0, st, n, nrow, (const double*)sky, period, w.c,
+                           (const int32_t*)w.rloc, (const int32_t*)w.boff, nb, w.flag + pass, pg);
+        rc = check_launch("k_unwrap scan/verify");
+    }
+    if (rc == PXL_OK) {
+        hipLaunchKernelGGL(k_unwrap_apply, dim3(g), dim3(256), 0, st, n, nrow, sky, period, ref, (const int32_t*)w.rloc,
+                           (const int32_t*)w.boff, nb, (const int32_t*)w.flag, gate);
+        hipLaunchKernelGGL(k_unwind_rows, dim3(nrow), dim3(64), 0, st, n, nrow, sky, period, ref, 1, (const int32_t*)w.flag);
+        rc = check_launch("k_unwrap_apply");
+    }
+    return rc;
+}
+
+static const int64_t kUnwindSerialMax = 4096;      // tiny batches: the exact serial kernel is already fast enough
 
 extern "C" {
 
@@ -187,18 +243,38 @@ int pxl_pix2sky_car_f64(const pxl_car_wcs* wcs, int64_t n, const double* pix, do
     hipStream_t st = (hipStream_t)stream;
     CarAffine c = car_affine(*wcs);
     const int mode = wrap_mode == PXL_WRAP_REWIND ? 1 : (wrap_mode == PXL_WRAP_UNWIND ? 2 : 0);
-    hipLaunchKernelGGL(k_pix2sky_pairs, dim3(stream_grid((n + PXL_UNR - 1) / PXL_UNR, 256)), dim3(256), 0, st, c, n,
-                       (const double2*)pix, (double2*)sky, mode);
-    int rc = check_launch("k_pix2sky_pairs");
-    if (rc || wrap_mode != PXL_WRAP_UNWIND) return rc;
-    return unwind_rows(n, 2, sky, PXL_TWOPI_D, 0.0, st);
+    const dim3 pgrid(stream_grid((n + PXL_UNR - 1) / PXL_UNR, 256));
+    if (wrap_mode != PXL_WRAP_UNWIND || n <= kUnwindSerialMax) {
+        hipLaunchKernelGGL(k_pix2sky_pairs, pgrid, dim3(256), 0, st, c, n, (const double2*)pix, (double2*)sky, mode,
+                           (const int32_t*)nullptr);
+        int rc = check_launch("k_pix2sky_pairs");
+        if (rc || wrap_mode != PXL_WRAP_UNWIND) return rc;
+        hipLaunchKernelGGL(k_unwind_rows, dim3(2), dim3(64), 0, st, n, 2, sky, PXL_TWOPI_D, 0.0, 1, (const int32_t*)nullptr);
+        return check_launch("k_unwind_rows");
+    }
+    // safe=true on a long batch: fused rewind + verified scan; the multi-pass form only if its check fails
+    const uintptr_t pa = (uintptr_t)pix, sa = (uintptr_t)sky, bytes = (uintptr_t)n * 16;
+    if (pa != sa && pa < sa + bytes && sa < pa + bytes) return fail(PXL_EINVAL, "pix2sky: pix and sky may alias exactly or not at all");
+    UnwindWs w;
+    int rc = unwind_ws_alloc(n, 2, st, &w);
+    if (rc) return rc;
+    UwSrcPix2 src{c, (const double2*)pix, PXL_TWOPI_D, 0.0, 1.0 / PXL_TWOPI_D};
+    rc = unwind_fused(src, (double2*)sky, n, pa == sa, w, st);
+    if (rc == PXL_OK) {
+        const int32_t* failed = w.flag + 2;
+        hipLaunchKernelGGL(k_pix2sky_pairs, dim3(std::min(pgrid.x, 2048u)), dim3(256), 0, st, c, n, (const double2*)pix, (double2*)sky, 2, failed);
+        rc = check_launch("k_pix2sky_pairs");
+        if (rc == PXL_OK) rc = unwind_multipass(n, 2, sky, PXL_TWOPI_D, 0.0, w, failed, st);
+    }
+    return unwind_ws_free(&w, st, rc);
 }
 
 int pxl_rewind_f64(double* a, int64_t n, double period, double ref_angle, void* stream) {
     if (n < 0 || (n > 0 && !a)) return fail(PXL_EINVAL, "rewind: null buffer or negative n");
     if (!(period > 0.0) || !std::isfinite(period) || !std::isfinite(ref_angle)) return fail(PXL_EINVAL, "rewind: period must be positive and finite");
     if (n == 0) return PXL_OK;
-    hipLaunchKernelGGL(k_rewind, dim3(stream_grid((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, n, a, period, ref_angle, 0);
+    hipLaunchKernelGGL(k_rewind, dim3(stream_grid((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, n, a, period, ref_angle, 0,
+                       (const int32_t*)nullptr);
     return check_launch("k_rewind");
 }
 
@@ -209,10 +285,28 @@ int pxl_unwind_f64(double* a, int64_t n, int nrow, double period, double ref_ang
     if (nrow == 2 && ((uintptr_t)a & 15) != 0) return fail(PXL_EINVAL, "unwind: 2xN buffer must be 16-byte aligned");
     if (n == 0) return PXL_OK;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_rewind, dim3(stream_grid(((int64_t)nrow * n + 3) / 4, 256)), dim3(256), 0, st, (int64_t)nrow * n, a, period, ref_angle, 1);
-    int rc = check_launch("k_rewind");
+    const dim3 rgrid(stream_grid(((int64_t)nrow * n + 3) / 4, 256));
+    if (n <= kUnwindSerialMax) {
+        hipLaunchKernelGGL(k_unwind_rows, dim3(nrow), dim3(64), 0, st, n, nrow, a, period, ref_angle, 0, (const int32_t*)nullptr);
+        return check_launch("k_unwind_rows");
+    }
+    UnwindWs w;
+    int rc = unwind_ws_alloc(n, nrow, st, &w);
     if (rc) return rc;
-    return unwind_rows(n, nrow, a, period, ref_angle, st);
+    if (nrow == 2) {
+        UwSrcAng2 src{(const double2*)a, period, ref_angle, 1.0 / period};
+        rc = unwind_fused(src, (double2*)a, n, true, w, st);
+    } else {
+        UwSrcAng1 src{(const double*)a, period, ref_angle, 1.0 / period};
+        rc = unwind_fused(src, a, n, true, w, st);
+    }
+    if (rc == PXL_OK) {
+        const int32_t* failed = w.flag + 2;
+        hipLaunchKernelGGL(k_rewind, dim3(std::min(rgrid.x, 2048u)), dim3(256), 0, st, (int64_t)nrow * n, a, period, ref_angle, 1, failed);
+        rc = check_launch("k_rewind");
+        if (rc == PXL_OK) rc = unwind_multipass(n, nrow, a, period, ref_angle, w, failed, st);
+    }
+    return unwind_ws_free(&w, st, rc);
 }
 
 int pxl_pix2sky_car_soa_f64(const pxl_car_wcs* wcs, int64_t n, const double* ipix, const double* jpix,

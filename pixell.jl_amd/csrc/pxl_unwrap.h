@@ -22,8 +22,9 @@
 #define PXL_SCAN_BLOCK (256 * PXL_SCAN_ITEMS)
 
 __global__ __launch_bounds__(256) void k_unwrap_incr(int64_t n, int nrow, const double* __restrict__ m2, double period,
-                                                     int8_t* __restrict__ c) {
+                                                     int8_t* __restrict__ c, const int32_t* __restrict__ gate) {
     // m2: nrow x N interleaved rewound values (nrow = 2 for coordinate batches, 1 for a plain vector); c: [nrow][n]
+    if (gate && *gate == 0) return;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
         for (int row = 0; row < nrow; ++row) {
@@ -41,7 +42,8 @@ __global__ __launch_bounds__(256) void k_scan_local(int64_t n, const TIN* __rest
     __shared__ int32_t wsum[4];
     if (gate && *gate == 0) return;         // second pass: only if the first verification found mismatches
     const int row = blockIdx.y;
-    const int64_t base = (int64_t)blockIdx.x * PXL_SCAN_BLOCK + (int64_t)threadIdx.x * PXL_SCAN_ITEMS;
+    for (int64_t blk = blockIdx.x; blk < nb; blk += gridDim.x) {
+    const int64_t base = blk * PXL_SCAN_BLOCK + (int64_t)threadIdx.x * PXL_SCAN_ITEMS;
     int32_t v[PXL_SCAN_ITEMS];
     int32_t run = 0;
 #pragma unroll
@@ -68,7 +70,9 @@ __global__ __launch_bounds__(256) void k_scan_local(int64_t n, const TIN* __rest
         int64_t k = base + i;
         if (k < n) rloc[row * n + k] = v[i] + excl;
     }
-    if (threadIdx.x == 255) bsum[row * nb + blockIdx.x] = woff + incl;
+    if (threadIdx.x == 255) bsum[row * nb + blk] = woff + incl;
+    __syncthreads();
+    }
 }
 
 // exclusive scan of the block totals (one block per coordinate row walks them with a running carry)
@@ -132,8 +136,10 @@ __global__ __launch_bounds__(256) void k_unwrap_verify(int64_t n, int nrow, cons
 
 __global__ __launch_bounds__(256) void k_unwrap_apply(int64_t n, int nrow, double* __restrict__ m2, double period, double ref,
                                                       const int32_t* __restrict__ rloc, const int32_t* __restrict__ boff,
-                                                      int64_t nb, const int32_t* __restrict__ flag) {
+                                                      int64_t nb, const int32_t* __restrict__ flag,
+                                                      const int32_t* __restrict__ gate) {
     // flag[0]: pass 1 found mismatches; flag[1]: pass 2 (run only then) still found some
+    if (gate && *gate == 0) return;         // the fused path already produced the answer
     if (flag[0] && flag[1]) return;         // unverified: the serial kernel produces the answer
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
@@ -151,6 +157,246 @@ __global__ __launch_bounds__(256) void k_unwrap_apply(int64_t n, int nrow, doubl
             m2[k] = y + ref;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused fast path of unwind!: the same verified integer scan, but the rewound values m never touch memory.
+//   k_unwind_sums   reads the input once, forms m in registers, sums the nominal increments of each 64*U-point
+//                   wave chunk, remembers the m just before each chunk and the first NaN of each coordinate row
+//   k_scan_wsums    exclusive scan of the chunk sums (one block)
+//   k_unwind_apply  reads the input again, re-forms m and the increments, scans them inside the wave, checks every
+//                   element against the reference's floating-point recurrence and writes y = m - r*P + ref
+// 48 B per 2xN point instead of ~124 B for the multi-pass form above, which stays as the fallback when the
+// check fails (steps within rounding of half a period).  NaN/Inf inputs are exact here: the recurrence turns
+// every element from the first NaN of a row onwards into NaN, which is what k_unwind_apply writes.
+// In-place calls verify first (no store) and store in a second, device-gated launch, so the input survives for
+// the fallback.
+// ------------------------------------------------------------------------------------------------
+#define PXL_UW_G 4          // 16-byte loads in flight per lane
+
+struct UwSrcPix2 {          // m = rewind(pix2sky affine) - ref, ref = 0   (pix2sky!(...; safe=true), car_proj.jl:104-112)
+    static constexpr int NROW = 2;
+    typedef double2 raw_t;
+    CarAffine c; const double2* p; double period, ref, rperiod;
+    __device__ inline raw_t load(int64_t k) const { return p[k]; }
+    __device__ inline raw_t zero() const { return make_double2(0.0, 0.0); }
+    __device__ inline void to_m(raw_t v, double* m) const {
+        const double a = p2s_ra(c, v.x), d = p2s_dec(c, v.y);
+        bool ok0, ok1;
+        m[0] = rewind_try(a, PXL_TWOPI_D, 0.0, rperiod, &ok0) - 0.0;
+        m[1] = rewind_try(d, PXL_TWOPI_D, 0.0, rperiod, &ok1) - 0.0;
+        if (__builtin_expect(!(ok0 && ok1), 0)) {                   // NaN/Inf or a huge quotient: library fmod
+            m[0] = rewind(a, PXL_TWOPI_D, 0.0, rperiod) - 0.0;
+            m[1] = rewind(d, PXL_TWOPI_D, 0.0, rperiod) - 0.0;
+        }
+    }
+    static __device__ inline void store(raw_t* out, int64_t k, const double* y) { out[k] = make_double2(y[0], y[1]); }
+};
+struct UwSrcAng2 {          // unwind!(angles2xN; dims=2): m = rewind(a) - ref   (enmap_ops.jl:26-28)
+    static constexpr int NROW = 2;
+    typedef double2 raw_t;
+    const double2* p; double period, ref, rperiod;
+    __device__ inline raw_t load(int64_t k) const { return p[k]; }
+    __device__ inline raw_t zero() const { return make_double2(0.0, 0.0); }
+    __device__ inline void to_m(raw_t v, double* m) const {
+        bool ok0, ok1;
+        m[0] = rewind_try(v.x, period, ref, rperiod, &ok0) - ref;
+        m[1] = rewind_try(v.y, period, ref, rperiod, &ok1) - ref;
+        if (__builtin_expect(!(ok0 && ok1), 0)) {
+            m[0] = rewind(v.x, period, ref, rperiod) - ref;
+            m[1] = rewind(v.y, period, ref, rperiod) - ref;
+        }
+    }
+    static __device__ inline void store(raw_t* out, int64_t k, const double* y) { out[k] = make_double2(y[0], y[1]); }
+};
+struct UwSrcAng1 {          // the same on a plain vector
+    static constexpr int NROW = 1;
+    typedef double raw_t;
+    const double* p; double period, ref, rperiod;
+    __device__ inline raw_t load(int64_t k) const { return p[k]; }
+    __device__ inline raw_t zero() const { return 0.0; }
+    __device__ inline void to_m(raw_t v, double* m) const { m[0] = rewind(v, period, ref, rperiod) - ref; m[1] = 0.0; }
+    static __device__ inline void store(raw_t* out, int64_t k, const double* y) { out[k] = y[0]; }
+};
+
+// wave-level data movement on the VALU (DPP / readlane) instead of ds_bpermute shuffles
+__device__ inline double uw_shr1(double v) {               // lane l gets lane l-1's value, lane 0 gets 0.0
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);      // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double uw_lane63(double v) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ inline int uw_scan64(int v) {                   // inclusive sum over the 64 lanes
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);        // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);        // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);        // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);        // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);       // row_bcast:15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);       // row_bcast:31 into rows 2, 3
+    return v;
+}
+
+// m, the m of the element before (mp) and the nominal increment c of this lane's element.  The increment is only a
+// guess (a multiply by ~1/P instead of the reference's division): k_unwind_apply checks every element with the
+// reference's own formula, and both kernels form the guess identically.
+template <class SRC>
+__device__ inline void uw_element(const SRC& s, int lane, int64_t k, bool valid, typename SRC::raw_t raw,
+                                  const double* mlast, double* m, double* mp, int* c) {
+    s.to_m(raw, m);
+#pragma unroll
+    for (int r = 0; r < SRC::NROW; ++r) {
+        const double up = uw_shr1(m[r]);
+        mp[r] = lane == 0 ? mlast[r] : up;
+        const double d = (m[r] - mp[r]) * s.rperiod;
+        int g = (valid && k > 0 && d == d) ? (int)rint(d) : 0;     // |d| <= 1 for rewound values
+        c[r] = g < -1 ? -1 : (g > 1 ? 1 : g);                       // keep the 16-bit scan fields consistent whatever d was
+    }
+}
+
+template <class SRC>
+__global__ __launch_bounds__(64) void k_unwind_sums(SRC src, int64_t n, int U, int2* __restrict__ wsum,
+                                                    double2* __restrict__ wprev, unsigned long long* __restrict__ firstnan) {
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * 64 * U;
+    double mlast[2];
+    src.to_m(base > 0 ? src.load(base - 1) : src.zero(), mlast);
+    if (lane == 0) wprev[blockIdx.x] = make_double2(mlast[0], mlast[1]);
+    int sum[2] = {0, 0};
+    unsigned long long nanat[2] = {~0ULL, ~0ULL};
+    for (int u0 = 0; u0 < U; u0 += PXL_UW_G) {
+        typename SRC::raw_t v[PXL_UW_G];
+#pragma unroll
+        for (int g = 0; g < PXL_UW_G; ++g) {
+            const int64_t k = base + (int64_t)(u0 + g) * 64 + lane;
+            v[g] = (k < n) ? src.load(k) : src.zero();
+        }
+#pragma unroll
+        for (int g = 0; g < PXL_UW_G; ++g) {
+            const int64_t k = base + (int64_t)(u0 + g) * 64 + lane;
+            double m[2], mp[2];
+            int c[2];
+            uw_element(src, lane, k, k < n, v[g], mlast, m, mp, c);
+#pragma unroll
+            for (int r = 0; r < SRC::NROW; ++r) {
+                sum[r] += c[r];
+                if (k < n && m[r] != m[r] && (unsigned long long)k < nanat[r]) nanat[r] = (unsigned long long)k;
+                mlast[r] = uw_lane63(m[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < SRC::NROW; ++r) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            sum[r] += __shfl_xor(sum[r], off, 64);
+            const unsigned long long o = __shfl_xor(nanat[r], off, 64);
+            nanat[r] = o < nanat[r] ? o : nanat[r];
+        }
+    }
+    if (lane == 0) {
+        wsum[blockIdx.x] = make_int2(sum[0], sum[1]);
+#pragma unroll
+        for (int r = 0; r < SRC::NROW; ++r)
+            if (nanat[r] != ~0ULL) atomicMin(&firstnan[r], nanat[r]);
+    }
+}
+
+// exclusive scan of the chunk sums, in place: one block sweeps tiles of 4096 entries (4 consecutive per thread)
+__global__ __launch_bounds__(1024) void k_scan_wsums(int64_t nw, int2* __restrict__ wsum) {
+    __shared__ int2 part[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int2 carry = make_int2(0, 0);
+    for (int64_t t0 = 0; t0 < nw; t0 += 4096) {
+        const int64_t b = t0 + 4 * (int64_t)threadIdx.x;
+        int2 v[4];
+        if (b + 3 < nw) {
+            const int4 q0 = *reinterpret_cast<const int4*>(wsum + b), q1 = *reinterpret_cast<const int4*>(wsum + b + 2);
+            v[0] = make_int2(q0.x, q0.y); v[1] = make_int2(q0.z, q0.w); v[2] = make_int2(q1.x, q1.y); v[3] = make_int2(q1.z, q1.w);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = (b + i < nw) ? wsum[b + i] : make_int2(0, 0);
+        }
+        const int2 t = make_int2(v[0].x + v[1].x + v[2].x + v[3].x, v[0].y + v[1].y + v[2].y + v[3].y);
+        const int2 incl = make_int2(uw_scan64(t.x), uw_scan64(t.y));
+        if (lane == 63) part[wave] = incl;
+        __syncthreads();
+        int2 run = make_int2(carry.x + incl.x - t.x, carry.y + incl.y - t.y);
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int2 pw = part[w];
+            if (w < wave) { run.x += pw.x; run.y += pw.y; }
+            carry.x += pw.x; carry.y += pw.y;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (b + i < nw) wsum[b + i] = run;
+            run.x += v[i].x; run.y += v[i].y;
+        }
+        __syncthreads();
+    }
+}
+
+template <class SRC, bool WRITE>
+__global__ __launch_bounds__(64) void k_unwind_apply(SRC src, typename SRC::raw_t* out, int64_t n, int U,
+                                                     const int2* __restrict__ woff, const double2* __restrict__ wprev,
+                                                     const unsigned long long* __restrict__ firstnan,
+                                                     int32_t* __restrict__ flag, const int32_t* __restrict__ skip_if_set) {
+    if (skip_if_set && *skip_if_set) return;
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * 64 * U;
+    const double P = src.period, rP = src.rperiod, ref = src.ref;
+    const double2 wp = wprev[blockIdx.x];
+    double mlast[2] = {wp.x, wp.y};
+    const int2 w0 = woff[blockIdx.x];
+    int carry[2] = {w0.x, w0.y};                       // r of the element just before this chunk
+    const unsigned long long fn[2] = {firstnan[0], firstnan[1]};
+    bool bad = false;
+    for (int u0 = 0; u0 < U; u0 += PXL_UW_G) {
+        typename SRC::raw_t v[PXL_UW_G];
+#pragma unroll
+        for (int g = 0; g < PXL_UW_G; ++g) {
+            const int64_t k = base + (int64_t)(u0 + g) * 64 + lane;
+            v[g] = (k < n) ? src.load(k) : src.zero();
+        }
+#pragma unroll
+        for (int g = 0; g < PXL_UW_G; ++g) {
+            const int64_t k = base + (int64_t)(u0 + g) * 64 + lane;
+            const bool valid = k < n;
+            double m[2], mp[2], y[2];
+            int c[2];
+            uw_element(src, lane, k, valid, v[g], mlast, m, mp, c);
+            // inclusive wave scan of both rows at once: (c + 1) in 16-bit fields, sums <= 128
+            int s = (c[0] + 1) | (SRC::NROW == 2 ? (c[1] + 1) << 16 : 0);
+            s = uw_scan64(s);
+            const int tot = __builtin_amdgcn_readlane(s, 63);
+#pragma unroll
+            for (int r = 0; r < SRC::NROW; ++r) {
+                const int field = r == 0 ? (s & 0xffff) : (s >> 16);
+                const int rr = carry[r] + field - (lane + 1);            // r_k
+                carry[r] += (r == 0 ? (tot & 0xffff) : (tot >> 16)) - 64;
+                mlast[r] = uw_lane63(m[r]);
+                if (!valid) continue;
+                if ((unsigned long long)k >= fn[r]) { y[r] = __builtin_nan("") + ref; continue; }
+                if (k > 0) {
+                    const double yprev = mp[r] - (double)(rr - c[r]) * P;   // y[k-1] as the reference forms it
+                    const double a = m[r] - yprev;
+                    const double qa = a * rP;
+                    // rint(a / P) == r_k is certain when the approximate quotient is well inside (r-1/2, r+1/2);
+                    // otherwise (ties, mismatches) divide exactly like the reference
+                    if (!(fabs(qa - (double)rr) < 0.5 - (fabs(qa) + 1.0) * 1e-14)) {
+                        const double q = a / P;
+                        if (!(rint(q) == (double)rr)) bad = true;
+                    }
+                }
+                y[r] = (k > 0 ? m[r] - (double)rr * P : m[r]) + ref;
+            }
+            if (WRITE && valid) SRC::store(out, k, y);
+        }
+    }
+    if (__any(bad) && lane == 0) atomicOr(flag, 1);
 }
 
 // Exact serial form (one wave per coordinate row, 64 dependent steps per 64 points): the fallback when the
@@ -181,7 +427,9 @@ __global__ __launch_bounds__(64) void k_unwind_rows(int64_t n, int nrow, double*
 }
 
 // rewind! on a flat array (enmap_ops.jl:15-19); sub_ref: also subtract ref (first half of unwind!)
-__global__ __launch_bounds__(256) void k_rewind(int64_t n, double* a, double period, double ref, int sub_ref) {
+__global__ __launch_bounds__(256) void k_rewind(int64_t n, double* a, double period, double ref, int sub_ref,
+                                                const int32_t* __restrict__ gate) {
+    if (gate && *gate == 0) return;
     const int64_t chunk = (int64_t)blockDim.x * 4;
     for (int64_t k0 = (int64_t)blockIdx.x * chunk + threadIdx.x; k0 < n; k0 += (int64_t)gridDim.x * chunk) {
         double v[4];
