@@ -65,7 +65,8 @@ size_t      pxl_last_error(char* buf, size_t n);
 int         pxl_device_count(void);
 
 /* ---- pix2sky!(shape, wcs::AbstractCARWCS, pixcoords::2xN, skycoords::2xN; safe)   car_proj.jl:92-115
- *      In-place (pix == sky) is allowed.  wrap_mode: PXL_WRAP_NONE | _REWIND | _UNWIND.              */
+ *      In-place (pix == sky) is allowed; partially overlapping buffers are refused (PXL_EINVAL) in _UNWIND mode.
+ *      wrap_mode: PXL_WRAP_NONE | _REWIND | _UNWIND.  _UNWIND handles at most 2^31-1 points per call.     */
 int pxl_pix2sky_car_f64(const pxl_car_wcs* wcs, int64_t n, const double* pix2xN, double* sky2xN,
                         int wrap_mode, void* stream);
 

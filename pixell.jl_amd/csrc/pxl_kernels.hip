@@ -69,6 +69,11 @@ static inline unsigned stream_grid(int64_t work_items, int block) {
     return (unsigned)nb;
 }
 
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
 #include "pxl_elementwise.h"
 #include "pxl_unwrap.h"
 #include "pxl_maps.h"
@@ -122,8 +127,9 @@ struct UnwindWs {
     unsigned long long* firstnan;                               // first NaN of each coordinate row
     int2* wsum; double2* wprev;                                 // fused form: per wave chunk
     int64_t nb, nw;
-    int U;
+    int U;                                                      // points per wave chunk / 64
 };
+
 
 static int unwind_ws_alloc(int64_t n, int nrow, hipStream_t st, UnwindWs* w) {
     w->nb = (n + PXL_SCAN_BLOCK - 1) / PXL_SCAN_BLOCK;
@@ -418,10 +424,6 @@ int pxl_posmap_tan_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64_t r
 }
 
 // ---- reprojection plan -------------------------------------------------------------------------
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
 
 int pxl_reproject_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], int64_t src_row0,
                               int64_t src_nrows, const pxl_car_wcs* wcs_out, const int64_t shape_out[2],

@@ -707,3 +707,24 @@ def test_float32_and_float64_agree(pj, dev):
     with pytest.raises(TypeError):
         plan = pj.ReprojectPlan(shape_in, wcs_in, shape_out, wcs_out, device=dev)
         plan.execute(a, torch.empty((shape_out[1], shape_out[0]), dtype=torch.float64, device=dev))
+
+
+def test_unwind_inplace_and_overlap(pj, O, dev):
+    """pix2sky!(m, buf, buf; safe=true) on a long batch: the in-place form verifies before it stores, so both the
+    clean case and the half-period-tie case (which falls back to the multi-pass form) match the oracle; partially
+    overlapping buffers are refused."""
+    g = _identity_wcs(pj)
+    n = 300_001
+    rng = np.random.default_rng(77)
+    walk = np.cumsum(rng.normal(0, 1.5, (n, 2)), axis=0)
+    buf = to_dev(walk, dev)
+    pj.pix2sky_(g, buf, buf, safe=True)
+    assert bits_equal(buf.cpu().numpy(), O.pix2sky(g[1], walk, O.WRAP_UNWIND))
+    k = np.arange(n, dtype=np.float64)
+    ties = np.stack([k * math.pi, 0.5 * walk[:, 1]], axis=1)
+    buf = to_dev(ties, dev)
+    pj.pix2sky_(g, buf, buf, safe=True)
+    assert bits_equal(buf.cpu().numpy(), O.pix2sky(g[1], ties, O.WRAP_UNWIND))
+    big = torch.zeros((n + 8, 2), dtype=torch.float64, device=dev)
+    with pytest.raises(RuntimeError):
+        pj.pix2sky_(g, big[:n], big[8:], safe=True)

@@ -49,7 +49,7 @@ def main():
     nb = 100_000_000
     small = pix[:nb].clone()
     small_out = torch.empty_like(small)
-    rec("pix2sky! 2xN safe=true (pairs + verified-scan unwrap), 1e8 pts",
+    rec("pix2sky! 2xN safe=true (fused rewind + verified-scan unwrap), 1e8 pts",
         timeit(lambda: pj.pix2sky_(g, small, small_out, safe=True), reps=5), 32.0 * nb, nb / 1e6, "Mpts")
     del small, small_out
     del pix, out, sky
