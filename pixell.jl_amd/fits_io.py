@@ -8,6 +8,7 @@ implemented -- no extensions, no scaling keywords, no compressed images.
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -77,11 +78,80 @@ def wcs_from_header(h):
                              (float(h.get("CRVAL1", 0.0)), float(h.get("CRVAL2", 0.0))), unit)
 
 
-def read_map(path, device="cuda", sel=None, verbose=False, dtype=None):
-    """read_map(path; sel) -> Enmap on the device.  sel = (sel_x, sel_y[, sel_c]) with the 1-based inclusive
-    selections of geometry.slice_geometry (e.g. ((11, 20), (21, 40), (1, 2)) for 11:20, 21:40, 1:2).
-    The element type follows the file (BITPIX -64 -> Float64, -32 -> Float32, like the reference's read);
-    dtype=torch.float64 widens a Float32 file on the device."""
+# ---- streaming between the file and HBM ------------------------------------------------------------
+# A 43200 x 21601 x 3 Float64 map is 22.4 GB on disk: the data block moves in chunks through two pinned host
+# buffers, so the host never holds more than 2 x CHUNK bytes of it, the H2D (or D2H) copy of one chunk runs on a
+# copy stream while the file system serves the next, and the byte swap happens on the device.
+
+def _chunk_bytes():
+    return max(4096, int(float(os.environ.get("PXL_FITS_CHUNK_MB", "128")) * (1 << 20)) & ~4095)
+
+
+class _Stager:
+    """Two pinned host buffers + two device staging buffers + a copy stream (double buffering)."""
+
+    def __init__(self, dev, nbytes):
+        self.dev = dev
+        self.nbytes = nbytes
+        self.host = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        self.view = [memoryview(h.numpy()) for h in self.host]
+        self.raw = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device=dev)
+        self.busy = [None, None]                  # event after which buffer b may be reused
+
+
+def _spans_to_chunks(spans, esz, chunk_elems):
+    """Split contiguous runs (file_offset, n_elements, dst_element_offset) into chunks of <= chunk_elems."""
+    for off, n, dst in spans:
+        done = 0
+        while done < n:
+            m = min(chunk_elems, n - done)
+            yield off + done * esz, m, dst + done
+            done += m
+
+
+def _decode(raw_ptr, out_ptr, n, bitpix, want, stream):
+    lib = _lib.load()
+    if want == torch.float32:
+        _lib.check(lib.pxl_fits_swap_f32(C.c_void_p(raw_ptr), C.c_void_p(out_ptr), n, stream))
+    else:
+        _lib.check(lib.pxl_fits_decode_f64(C.c_void_p(raw_ptr), C.c_void_p(out_ptr), n, bitpix, stream))
+
+
+def _read_spans(path, spans, out, bitpix, dev):
+    """File -> pinned host -> HBM -> big-endian decode into the flat tensor `out` (element offsets in spans)."""
+    esz = -bitpix // 8
+    total = sum(n for _, n, _ in spans)
+    if total == 0:
+        return
+    chunk = min(_chunk_bytes() // esz, max(n for _, n, _ in spans))
+    st = _Stager(dev, chunk * esz)
+    cur = torch.cuda.current_stream(dev)
+    s = C.c_void_p(cur.cuda_stream)
+    osz = out.element_size()
+    with open(path, "rb", buffering=0) as f, torch.cuda.device(dev):
+        for i, (off, n, dst) in enumerate(_spans_to_chunks(spans, esz, chunk)):
+            b = i & 1
+            if st.busy[b] is not None:
+                st.busy[b].synchronize()          # the copy and the decode that used this pair are done
+            f.seek(off)
+            got = f.readinto(st.view[b][:n * esz])
+            if got != n * esz:
+                raise ValueError("truncated FITS data block in %s" % path)
+            with torch.cuda.stream(st.copy_stream):
+                st.raw[b][:n * esz].copy_(st.host[b][:n * esz], non_blocking=True)
+                copied = torch.cuda.Event()
+                copied.record(st.copy_stream)
+            cur.wait_event(copied)
+            _decode(st.raw[b].data_ptr(), out.data_ptr() + dst * osz, n, bitpix, out.dtype, s)
+            st.busy[b] = torch.cuda.Event()
+            st.busy[b].record(cur)
+    for ev in st.busy:
+        if ev is not None:
+            ev.synchronize()                      # the staging buffers die with this call
+
+
+def _file_layout(path):
     h, offset = read_header(path)
     bitpix = h["BITPIX"]
     if bitpix not in (-64, -32):
@@ -89,32 +159,89 @@ def read_map(path, device="cuda", sel=None, verbose=False, dtype=None):
     naxis = h["NAXIS"]
     if naxis not in (2, 3):
         raise ValueError("NAXIS %d not supported" % naxis)
-    dims = [h["NAXIS%d" % (k + 1)] for k in range(naxis)]                      # (nx, ny[, nc]) = Julia shape
-    n = int(np.prod(dims))
-    raw = np.memmap(path, dtype=np.uint8, mode="r", offset=offset, shape=(n * (-bitpix // 8),))
-    dev = torch.device(device)
-    d_raw = torch.from_numpy(np.array(raw)).to(dev)            # one host copy of the data block, then H2D
+    dims = [int(h["NAXIS%d" % (k + 1)]) for k in range(naxis)]                  # (nx, ny[, nc]) = Julia shape
+    need = offset + int(np.prod(dims)) * (-bitpix // 8)
+    if os.path.getsize(path) < need:
+        raise ValueError("truncated FITS data block in %s" % path)
+    return h, offset, bitpix, dims
+
+
+def _want_dtype(bitpix, dtype):
     want = dtype if dtype is not None else (torch.float64 if bitpix == -64 else torch.float32)
-    out = torch.empty(tuple(reversed(dims)), dtype=want, device=dev)
-    with torch.cuda.device(dev):
-        s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        if want == torch.float32:
-            if bitpix != -32:
-                raise ValueError("a BITPIX -64 file cannot be read as Float32 without loss; read it as Float64")
-            _lib.check(_lib.load().pxl_fits_swap_f32(C.c_void_p(d_raw.data_ptr()), C.c_void_p(out.data_ptr()), n, s))
-        else:
-            _lib.check(_lib.load().pxl_fits_decode_f64(C.c_void_p(d_raw.data_ptr()), C.c_void_p(out.data_ptr()), n, bitpix, s))
-    wcs = wcs_from_header(h)
-    # IAU <-> COSMO (enmap.jl:178-195,206-211): flip U (third Stokes plane) when the file says POLCCONV = IAU
-    if "STOKES" in [v for v in h.values() if isinstance(v, str)] and h.get("POLCCONV", "COSMO") == "IAU" and naxis == 3:
+    if want == torch.float32 and bitpix != -32:
+        raise ValueError("a BITPIX -64 file cannot be read as Float32 without loss; read it as Float64")
+    if want not in (torch.float32, torch.float64):
+        raise TypeError("maps are Float64 or Float32")
+    return want
+
+
+def _flip_u_if_iau(h, out, comps, verbose):
+    """IAU <-> COSMO (enmap.jl:178-195,206-211): flip U (third Stokes plane) when the file says POLCCONV = IAU.
+    comps = 0-based file component held by each plane of `out`."""
+    if "STOKES" in [v for v in h.values() if isinstance(v, str)] and h.get("POLCCONV", "COSMO") == "IAU" and out.dim() == 3:
         if verbose:
             print("convert to IAU: flip U")
-        if dims[2] >= 3:
-            out[2].neg_()
-    m = Enmap(out, wcs)
+        for plane, c in enumerate(comps):
+            if c == 2:
+                out[plane].neg_()
+
+
+def read_map_rows(path, row0, nrows, device="cuda", comps=None, dtype=None, verbose=False):
+    """Rows [row0, row0 + nrows) (0-based) of every component of a FITS map, straight into HBM: the declination
+    strip of one rank of a sharded job (rows are contiguous on disk, so only those bytes are read).  Returns
+    (tensor ([nc,] nrows, nx), full Julia shape, WCS of the FULL map) -- windows into the full geometry, like
+    the sharded operator wants them (sharding.py)."""
+    h, offset, bitpix, dims = _file_layout(path)
+    nx, ny = dims[0], dims[1]
+    nc_file = dims[2] if len(dims) == 3 else 1
+    if row0 < 0 or nrows < 0 or row0 + nrows > ny:
+        raise ValueError("rows [%d, %d) are outside the map (%d rows)" % (row0, row0 + nrows, ny))
+    comps = list(range(nc_file)) if comps is None else [int(c) for c in comps]
+    if any(c < 0 or c >= nc_file for c in comps):
+        raise ValueError("component outside the file")
+    dev = torch.device(device)
+    want = _want_dtype(bitpix, dtype)
+    esz = -bitpix // 8
+    shape = (len(comps), nrows, nx) if len(dims) == 3 else (nrows, nx)
+    out = torch.empty(shape, dtype=want, device=dev)
+    spans = [(offset + (c * ny + row0) * nx * esz, nrows * nx, k * nrows * nx) for k, c in enumerate(comps)]
+    # neighbouring components of a full-height read are one contiguous run
+    merged = []
+    for sp in spans:
+        if merged and merged[-1][0] + merged[-1][1] * esz == sp[0] and merged[-1][2] + merged[-1][1] == sp[2]:
+            merged[-1] = (merged[-1][0], merged[-1][1] + sp[1], merged[-1][2])
+        else:
+            merged.append(sp)
+    _read_spans(path, merged, out, bitpix, dev)
+    _flip_u_if_iau(h, out, comps, verbose)
+    return out, tuple(dims), wcs_from_header(h)
+
+
+def read_map(path, device="cuda", sel=None, verbose=False, dtype=None):
+    """read_map(path; sel) -> Enmap on the device.  sel = (sel_x, sel_y[, sel_c]) with the 1-based inclusive
+    selections of geometry.slice_geometry (e.g. ((11, 20), (21, 40), (1, 2)) for 11:20, 21:40, 1:2).
+    The element type follows the file (BITPIX -64 -> Float64, -32 -> Float32, like the reference's read);
+    dtype=torch.float64 widens a Float32 file on the device.  The data block is streamed (see _read_spans); a
+    selection of whole rows (all of RA, a unit-step DEC range, a unit-step component range) reads only its bytes."""
+    from .geometry import _as_range, slice_geometry
+    h, offset, bitpix, dims = _file_layout(path)
+    nx, ny = dims[0], dims[1]
+    nc_file = dims[2] if len(dims) == 3 else 1
+    rx = ry = rc = None
     if sel is not None:
-        m = m.getindex(*sel)
-    return m
+        rx, ry = _as_range(sel[0], nx), _as_range(sel[1], ny)
+        rc = _as_range(sel[2], nc_file) if len(sel) > 2 and len(dims) == 3 else None
+    whole_rows = sel is not None and rx.first == 1 and rx.step == 1 and rx.length == nx and ry.step == 1 and ry.length > 0 \
+        and (rc is None or (rc.step == 1 and rc.length > 0))
+    if sel is None or whole_rows:
+        row0, nrows = (0, ny) if sel is None else (ry.first - 1, ry.length)
+        comps = None if rc is None else list(range(rc.first - 1, rc.last))
+        data, _, wcs = read_map_rows(path, row0, nrows, device=device, comps=comps, dtype=dtype, verbose=verbose)
+        if sel is not None:
+            _, wcs = slice_geometry((nx, ny), wcs, rx, ry)
+        return Enmap(data, wcs)
+    data, _, wcs = read_map_rows(path, 0, ny, device=device, dtype=dtype, verbose=verbose)
+    return Enmap(data, wcs).getindex(*sel)
 
 
 def _card(key, value, comment=""):
@@ -155,15 +282,39 @@ def write_map(path, m: Enmap):
     header = "".join(cards)
     header += " " * (-len(header) % BLOCK)
     n = data.numel()
-    raw = torch.empty(n, dtype=torch.int32 if f32 else torch.int64, device=data.device)
-    with torch.cuda.device(data.device):
-        s = C.c_void_p(torch.cuda.current_stream(data.device).cuda_stream)
-        if f32:
-            _lib.check(_lib.load().pxl_fits_swap_f32(C.c_void_p(data.data_ptr()), C.c_void_p(raw.data_ptr()), n, s))
-        else:
-            _lib.check(_lib.load().pxl_fits_encode_f64(C.c_void_p(data.data_ptr()), C.c_void_p(raw.data_ptr()), n, s))
-    payload = raw.cpu().numpy().tobytes()
+    esz = 4 if f32 else 8
+    dev = data.device
+    flat = data.reshape(-1)
+    lib = _lib.load()
     with open(path, "wb") as f:
         f.write(header.encode("ascii"))
-        f.write(payload)
-        f.write(b"\0" * (-len(payload) % BLOCK))
+        if n:
+            chunk = min(_chunk_bytes() // esz, n)
+            st = _Stager(dev, chunk * esz)
+            cur = torch.cuda.current_stream(dev)
+            s = C.c_void_p(cur.cuda_stream)
+            pending = None                          # (buffer, bytes, event) of the chunk on its way to the host
+            with torch.cuda.device(dev):
+                for i, (_, m, at) in enumerate(_spans_to_chunks([(0, n, 0)], esz, chunk)):
+                    b = i & 1
+                    src = flat.data_ptr() + at * esz
+                    if f32:
+                        _lib.check(lib.pxl_fits_swap_f32(C.c_void_p(src), C.c_void_p(st.raw[b].data_ptr()), m, s))
+                    else:
+                        _lib.check(lib.pxl_fits_encode_f64(C.c_void_p(src), C.c_void_p(st.raw[b].data_ptr()), m, s))
+                    encoded = torch.cuda.Event()
+                    encoded.record(cur)
+                    with torch.cuda.stream(st.copy_stream):
+                        st.copy_stream.wait_event(encoded)
+                        st.host[b][:m * esz].copy_(st.raw[b][:m * esz], non_blocking=True)
+                        arrived = torch.cuda.Event()
+                        arrived.record(st.copy_stream)
+                    if pending is not None:         # write chunk i-1 while chunk i is encoded and copied
+                        pb, pbytes, pev = pending
+                        pev.synchronize()
+                        f.write(st.view[pb][:pbytes])
+                    pending = (b, m * esz, arrived)
+                pb, pbytes, pev = pending
+                pev.synchronize()
+                f.write(st.view[pb][:pbytes])
+        f.write(b"\0" * (-(n * esz) % BLOCK))
