@@ -16,7 +16,7 @@ from .enmap import Enmap, NoWCS, getwcs
 from .ops import (ReprojectPlan, fill_random_, fill_sphere_points_, pix2sky, pix2sky_, pix2sky_rewind,
                   pixareamap, pixareamap_, posmap, reproject, rewind_, sample_bilinear, sky2pix, sky2pix_,
                   sky2pix_broadcast, unwind_)
-from .sharding import DecStripReprojector, strip_bounds
+from .sharding import DecStripLayout, DecStripReprojector, strip_bounds
 from .fits_io import read_header, read_map, read_map_rows, wcs_from_header, write_map
 
 # unit shortcuts, Pixell.jl:46-48 (angles are plain radians here)

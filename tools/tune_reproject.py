@@ -28,18 +28,29 @@ def main():
     ap.add_argument("--workload", default="cfg4")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--strip", default=None, help="R/W: time the declination strip of rank R of W (interior rows only)")
     ap.add_argument("variants", nargs="+")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     shape_in, wcs_in, shape_out, wcs_out, desc = bench.workload_geometry(args.workload)
     nx, ny, nc = shape_in
     nxo, nyo = shape_out
+    src_rows = dst_rows = None
+    r0, nr = 0, nyo
+    if args.strip:
+        rank, world = (int(v) for v in args.strip.split("/"))
+        lay = pj.DecStripLayout(shape_in, wcs_in, shape_out, wcs_out, rank, world)
+        src_rows, dst_rows = lay.src_window, lay.dst_window
+        r0, nr = lay.interior[0], lay.interior[1] - lay.interior[0]
+        desc += "  [strip %d/%d: %d source rows, %d interior output rows]" % (rank, world, src_rows[1], nr)
+    ny_s = src_rows[1] if src_rows else ny
+    nyo_s = dst_rows[1] if dst_rows else nyo
     if args.dtype == "f32":
-        src = torch.randn((nc, ny, nx), dtype=torch.float32, device=dev)
-        dst = torch.empty((nc, nyo, nxo), dtype=torch.float32, device=dev)
+        src = torch.randn((nc, ny_s, nx), dtype=torch.float32, device=dev)
+        dst = torch.empty((nc, nyo_s, nxo), dtype=torch.float32, device=dev)
     else:
-        src = torch.empty((nc, ny, nx), dtype=torch.float64, device=dev)
-        dst = torch.empty((nc, nyo, nxo), dtype=torch.float64, device=dev)
+        src = torch.empty((nc, ny_s, nx), dtype=torch.float64, device=dev)
+        dst = torch.empty((nc, nyo_s, nxo), dtype=torch.float64, device=dev)
         pj.fill_random_(src, 1234)
     plans = []
     for v in args.variants:
@@ -49,21 +60,21 @@ def main():
             if kv:
                 k, val = kv.split("=")
                 os.environ[KEYS[k]] = val
-        plans.append(pj.ReprojectPlan(shape_in, wcs_in, shape_out, wcs_out, device=dev))
+        plans.append(pj.ReprojectPlan(shape_in, wcs_in, shape_out, wcs_out, src_rows=src_rows, dst_rows=dst_rows, device=dev))
     for pl in plans:
         pl.build_tables()
-        pl.execute_rows(src, dst, 0, nyo)       # warm-up
+        pl.execute_rows(src, dst, r0, nr)       # warm-up
     torch.cuda.synchronize()
     times = [[] for _ in plans]
     for _ in range(args.rounds):
         for i, pl in enumerate(plans):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            pl.execute_rows(src, dst, 0, nyo)
+            pl.execute_rows(src, dst, r0, nr)
             e1.record()
             torch.cuda.synchronize()
             times[i].append(e0.elapsed_time(e1))
-    alg = (4.0 if args.dtype == "f32" else 8.0) * nc * (nx * ny + nxo * nyo)
+    alg = (4.0 if args.dtype == "f32" else 8.0) * nc * (nx * ny_s + nxo * nr)
     print("workload:", desc)
     for v, t in zip(args.variants, times):
         t = sorted(t)
