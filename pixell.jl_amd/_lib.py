@@ -61,6 +61,11 @@ SIGNATURES = {
     "pxl_reproject_generic_bilinear_f64": (C.c_int, [_WP, C.c_int, _SHP, _P, _WP, C.c_int, _SHP, _P, _P]),
     "pxl_sample_car_bilinear_f64": (C.c_int, [_WP, _SHP, _P, _I64, _I64, _I64, _P, _P, _P]),
     "pxl_sample_car_bilinear_f32": (C.c_int, [_WP, _SHP, _P, _I64, _I64, _I64, _P, _P, _P]),
+    "pxl_sample_pairs_elems": (_I64, [_SHP, _I64]),
+    "pxl_sample_build_pairs_f64": (C.c_int, [_SHP, _P, _I64, _P, _P]),
+    "pxl_sample_build_pairs_f32": (C.c_int, [_SHP, _P, _I64, _P, _P]),
+    "pxl_sample_car_bilinear_pairs_f64": (C.c_int, [_WP, _SHP, _P, _I64, _I64, _I64, _P, _P, _P]),
+    "pxl_sample_car_bilinear_pairs_f32": (C.c_int, [_WP, _SHP, _P, _I64, _I64, _I64, _P, _P, _P]),
     "pxl_fits_decode_f64": (C.c_int, [_P, _P, _I64, C.c_int, _P]),
     "pxl_fits_encode_f64": (C.c_int, [_P, _P, _I64, _P]),
     "pxl_fits_swap_f32": (C.c_int, [_P, _P, _I64, _P]),

@@ -770,6 +770,74 @@ int pxl_sample_car_bilinear_f32(const pxl_car_wcs* wcs_in, const int64_t shape_i
     return sample_impl(wcs_in, shape_in, src, src_row0, src_nrows, n, sky, out, stream, 4);
 }
 
+// ---- row-pair layout (pxl_sample.h): caller-owned buffer of pxl_sample_pairs_elems() map elements
+int64_t pxl_sample_pairs_elems(const int64_t shape_in[3], int64_t src_nrows) {
+    if (!shape_in || shape_in[0] < 1 || shape_in[1] < 1 || shape_in[2] < 1 || src_nrows < 0 || src_nrows > shape_in[1]) {
+        fail(PXL_EINVAL, "sample_pairs_elems: invalid shape or window");
+        return -1;
+    }
+    return 2 * shape_in[0] * (src_nrows + 1) * shape_in[2];
+}
+
+static int build_pairs_impl(const int64_t shape_in[3], const void* src, int64_t src_nrows, void* pairs, void* stream, int dtype) {
+    if (pxl_sample_pairs_elems(shape_in, src_nrows) < 0) return PXL_EINVAL;
+    if (!pairs || (!src && src_nrows > 0)) return fail(PXL_EINVAL, "sample_build_pairs: null buffer");
+    if (((uintptr_t)pairs & (2 * dtype - 1)) != 0) return fail(PXL_EINVAL, "sample_build_pairs: pair buffer must be aligned to two elements");
+    if (shape_in[2] > 65535) return fail(PXL_EINVAL, "sample_build_pairs: more than 65535 components");
+    const int64_t nx = shape_in[0], tiles = (src_nrows + 1 + PXL_POS_ROWS - 1) / PXL_POS_ROWS;
+    if (tiles > 65535) return fail(PXL_EINVAL, "sample_build_pairs: more than %lld rows per call", 65535LL * PXL_POS_ROWS);
+    dim3 grid((unsigned)((nx + 255) / 256), (unsigned)tiles, (unsigned)shape_in[2]);
+    if (dtype == 4)
+        hipLaunchKernelGGL((k_build_rowpairs<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, nx, src_nrows, (float2*)pairs);
+    else
+        hipLaunchKernelGGL((k_build_rowpairs<double>), grid, dim3(256), 0, (hipStream_t)stream, (const double*)src, nx, src_nrows, (double2*)pairs);
+    return check_launch("k_build_rowpairs");
+}
+
+int pxl_sample_build_pairs_f64(const int64_t shape_in[3], const double* src, int64_t src_nrows, double* pairs, void* stream) {
+    return build_pairs_impl(shape_in, src, src_nrows, pairs, stream, 8);
+}
+
+int pxl_sample_build_pairs_f32(const int64_t shape_in[3], const float* src, int64_t src_nrows, float* pairs, void* stream) {
+    return build_pairs_impl(shape_in, src, src_nrows, pairs, stream, 4);
+}
+
+static int sample_pairs_impl(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], const void* pairs, int64_t src_row0,
+                             int64_t src_nrows, int64_t n, const double* sky, void* out, void* stream, int dtype) {
+    if (!wcs_ok(wcs_in) || !shape_in) return fail(PXL_EINVAL, "sample_pairs: invalid WCS/shape");
+    if (shape_in[0] < 1 || shape_in[1] < 1 || shape_in[2] < 1) return fail(PXL_EINVAL, "sample_pairs: shapes must be positive");
+    if (src_row0 < 0 || src_nrows < 0 || src_row0 + src_nrows > shape_in[1])
+        return fail(PXL_EINVAL, "sample_pairs: source window outside the map");
+    if (n < 0 || (n > 0 && (!sky || !out || !pairs))) return fail(PXL_EINVAL, "sample_pairs: null buffer or negative n");
+    if (((uintptr_t)sky & 15) != 0) return fail(PXL_EINVAL, "sample_pairs: 2xN buffer must be 16-byte aligned");
+    if (((uintptr_t)pairs & (2 * dtype - 1)) != 0) return fail(PXL_EINVAL, "sample_pairs: pair buffer must be aligned to two elements");
+    if (n == 0) return PXL_OK;
+    Sky2Pix s = sky2pix_setup(*wcs_in, shape_in[0], shape_in[1], 1, PXL_FORM_RECIP);
+    int periodic = fabs((double)shape_in[0] * fabs(wcs_in->cdelt[0] * wcs_in->unit) - PXL_TWOPI_D) < 1e-8;
+    dim3 grid(stream_grid((n + PXL_SUNR - 1) / PXL_SUNR, 256));
+    if (dtype == 4)
+        hipLaunchKernelGGL((k_sample_pairs<float>), grid, dim3(256), 0, (hipStream_t)stream, s, (const float2*)pairs,
+                           shape_in[0], shape_in[1], (int32_t)shape_in[2], src_row0, src_nrows, periodic, n,
+                           (const double2*)sky, (float*)out);
+    else
+        hipLaunchKernelGGL((k_sample_pairs<double>), grid, dim3(256), 0, (hipStream_t)stream, s, (const double2*)pairs,
+                           shape_in[0], shape_in[1], (int32_t)shape_in[2], src_row0, src_nrows, periodic, n,
+                           (const double2*)sky, (double*)out);
+    return check_launch("k_sample_pairs");
+}
+
+int pxl_sample_car_bilinear_pairs_f64(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], const double* pairs,
+                                      int64_t src_row0, int64_t src_nrows, int64_t n, const double* sky, double* out,
+                                      void* stream) {
+    return sample_pairs_impl(wcs_in, shape_in, pairs, src_row0, src_nrows, n, sky, out, stream, 8);
+}
+
+int pxl_sample_car_bilinear_pairs_f32(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], const float* pairs,
+                                      int64_t src_row0, int64_t src_nrows, int64_t n, const double* sky, float* out,
+                                      void* stream) {
+    return sample_pairs_impl(wcs_in, shape_in, pairs, src_row0, src_nrows, n, sky, out, stream, 4);
+}
+
 int pxl_fits_decode_f64(const void* raw_be, double* dst, int64_t n, int bitpix, void* stream) {
     if (n < 0 || (n > 0 && (!raw_be || !dst))) return fail(PXL_EINVAL, "fits_decode: null buffer or negative n");
     if (bitpix != -64 && bitpix != -32) return fail(PXL_EINVAL, "fits_decode: BITPIX %d not supported (only -64, -32)", bitpix);

@@ -107,3 +107,89 @@ __global__ __launch_bounds__(256) void k_sample_bilinear(Sky2Pix s, const T* __r
         }
     }
 }
+
+// ---- row-pair layout for scattered sampling.  The gather above is bound by random 64-byte sector fetches (about
+// 2.25 per point: the two taps of a row are neighbours, the two rows are nx elements apart).  In the pair layout
+// element (p, i) holds (v[p-1][i], v[p][i]) -- rows outside the resident window read as zero, p = 0 .. nrows -- so
+// the whole 2x2 neighbourhood of a point is two ADJACENT 2-element entries: about 1.25 sectors per point, for
+// twice the map's footprint (288 GB of HBM is there to be used) and one streaming pass to build it.  Same taps,
+// same arithmetic: results are bit-identical to k_sample_bilinear.
+template <typename T> struct Vec2T;
+template <> struct Vec2T<double> { typedef double2 type; };
+template <> struct Vec2T<float>  { typedef float2 type; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_build_rowpairs(const T* __restrict__ src, int64_t nx, int64_t nrows,
+                                                        typename Vec2T<T>::type* __restrict__ pairs) {
+    // block = (256 columns, PXL_POS_ROWS pair rows, component): a lane walks down its column carrying the row above
+    typedef typename Vec2T<T>::type T2;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nx) return;
+    const int64_t c = blockIdx.z;
+    const T* pl = src + c * nx * nrows;
+    T2* out = pairs + c * nx * (nrows + 1);
+    const int64_t p0 = (int64_t)blockIdx.y * PXL_POS_ROWS;
+    const int64_t p1 = (p0 + PXL_POS_ROWS <= nrows) ? p0 + PXL_POS_ROWS : nrows + 1;     // pair rows [p0, p1)
+    T above = (p0 >= 1) ? pl[(p0 - 1) * nx + i] : (T)0;
+    for (int64_t p = p0; p < p1; ++p) {
+        const T here = (p < nrows) ? pl[p * nx + i] : (T)0;
+        T2 v; v.x = above; v.y = here;
+        out[p * nx + i] = v;
+        above = here;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_sample_pairs(Sky2Pix s, const typename Vec2T<T>::type* __restrict__ pairs,
+                                                      int64_t nx, int64_t ny, int32_t nc, int64_t row0, int64_t nrows,
+                                                      int periodic, int64_t n, const double2* __restrict__ sky,
+                                                      T* __restrict__ out) {
+    typedef typename Vec2T<T>::type T2;
+    const int64_t chunk = (int64_t)blockDim.x * PXL_SUNR;
+    const int64_t plane = nx * (nrows + 1);
+    for (int64_t k0 = (int64_t)blockIdx.x * chunk + threadIdx.x; k0 < n; k0 += (int64_t)gridDim.x * chunk) {
+        double2 ad[PXL_SUNR];
+#pragma unroll
+        for (int u = 0; u < PXL_SUNR; ++u) {
+            int64_t k = k0 + u * blockDim.x;
+            ad[u] = (k < n) ? sky[k] : make_double2(0.0, 0.0);
+        }
+        int64_t oa[PXL_SUNR], ob[PXL_SUNR];                  // pair-entry offsets of columns i0 and i0 + 1, -1 = zeros
+        double fx[PXL_SUNR], fy[PXL_SUNR];
+        bool fin[PXL_SUNR];
+#pragma unroll
+        for (int u = 0; u < PXL_SUNR; ++u) {
+            double x = s2p_x(s, ad[u].x), y = s2p_y(s, ad[u].y);
+            fin[u] = isfinite(x) && isfinite(y);
+            int32_t i0, j0;
+            split_cell(x, &i0, &fx[u]);
+            split_cell(y, &j0, &fy[u]);
+            int64_t ia = i0, ib = (int64_t)i0 + 1;
+            bool oka = true, okb = true;
+            if (periodic) { ia = wrap_col(ia, nx); ib = wrap_col(ib, nx); }
+            else { oka = (ia >= 1 && ia <= nx); okb = (ib >= 1 && ib <= nx); }
+            const int64_t p = (int64_t)j0 - row0;            // entry p holds resident rows p-1 (cell row j0) and p
+            const bool rows = (p >= 0 && p <= nrows);
+            oa[u] = (rows && oka) ? p * nx + (ia - 1) : -1;
+            ob[u] = (rows && okb) ? p * nx + (ib - 1) : -1;
+        }
+        for (int c = 0; c < nc; ++c) {
+            const T2* pl = pairs + (int64_t)c * plane;
+            T2 a[PXL_SUNR], b[PXL_SUNR];
+#pragma unroll
+            for (int u = 0; u < PXL_SUNR; ++u) {
+                T2 z; z.x = (T)0; z.y = (T)0;
+                a[u] = oa[u] >= 0 ? pl[oa[u]] : z;
+                b[u] = ob[u] >= 0 ? pl[ob[u]] : z;
+            }
+#pragma unroll
+            for (int u = 0; u < PXL_SUNR; ++u) {
+                int64_t k = k0 + u * blockDim.x;
+                double top = (1 - fx[u]) * (double)a[u].x + fx[u] * (double)b[u].x;
+                double bot = (1 - fx[u]) * (double)a[u].y + fx[u] * (double)b[u].y;
+                double v = (1 - fy[u]) * top + fy[u] * bot;
+                if (k < n) out[(int64_t)c * n + k] = (T)(fin[u] ? v : __builtin_nan(""));
+            }
+        }
+    }
+}

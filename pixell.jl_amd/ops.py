@@ -400,18 +400,61 @@ def _reproject_generic(m: Enmap, shape_out, wcs_out, out=None) -> Enmap:
     return out
 
 
-def sample_bilinear(m: Enmap, skycoords: torch.Tensor, src_rows=None, full_shape=None) -> torch.Tensor:
+class SamplePairs:
+    """Row-pair copy of a map for scattered sampling (pxl_sample_build_pairs_*): twice the footprint, about half
+    the random sector fetches per point.  Build once per map, pass to sample_bilinear(..., pairs=...)."""
+
+    def __init__(self, m: Enmap, src_rows=None, full_shape=None, out: torch.Tensor = None):
+        data = _dev_map(m.data, "map data")
+        _require_car(m.wcs)
+        self.wcs = m.wcs
+        self.shape = tuple(m.shape if full_shape is None else full_shape)
+        self.nc = data.shape[0] if data.dim() == 3 else 1
+        self.src_rows = (0, self.shape[1]) if src_rows is None else (int(src_rows[0]), int(src_rows[1]))
+        self.dtype = data.dtype
+        lib = _lib.load()
+        shp = _lib.shape_arr((self.shape[0], self.shape[1], self.nc))
+        n = lib.pxl_sample_pairs_elems(shp, self.src_rows[1])
+        if n < 0:
+            raise _lib.PixellHipError(-22, _lib.last_error())
+        if data.numel() != self.nc * self.src_rows[1] * self.shape[0]:
+            raise ValueError("map data does not match the resident window")
+        self.data = out if out is not None else torch.empty(n, dtype=data.dtype, device=data.device)
+        if self.data.numel() != n or self.data.dtype != data.dtype or not self.data.is_contiguous():
+            raise ValueError("pair buffer must hold %d contiguous %s elements" % (n, data.dtype))
+        self.rebuild(data)
+
+    def rebuild(self, data: torch.Tensor):
+        """Re-derive the pair copy after the map changed (one streaming pass)."""
+        data = _dev_map(data, "map data")
+        lib = _lib.load()
+        fn = lib.pxl_sample_build_pairs_f32 if data.dtype == torch.float32 else lib.pxl_sample_build_pairs_f64
+        with torch.cuda.device(data.device):
+            _lib.check(fn(_lib.shape_arr((self.shape[0], self.shape[1], self.nc)), _ptr(data), self.src_rows[1],
+                          _ptr(self.data), _stream(data)))
+        return self
+
+
+def sample_bilinear(m: Enmap, skycoords: torch.Tensor, src_rows=None, full_shape=None, pairs: SamplePairs = None) -> torch.Tensor:
     """Bilinear sample of every component of `m` at a 2xN batch of (ra, dec): fused
     sky2pix!(safe=true) [car_proj.jl:165-193] + 2x2 gather.  Returns a (nc, N) tensor.
-    src_rows/full_shape describe `m.data` as a declination strip of a larger map."""
+    src_rows/full_shape describe `m.data` as a declination strip of a larger map.  pairs: a SamplePairs copy of
+    the same map (then `m` may be None): same result, fewer random memory sectors per point."""
     sky = _dev_f64(skycoords, "skycoords")
+    lib = _lib.load()
+    if pairs is not None:
+        out = torch.empty((pairs.nc, sky.shape[0]), dtype=pairs.dtype, device=sky.device)
+        fn = lib.pxl_sample_car_bilinear_pairs_f32 if pairs.dtype == torch.float32 else lib.pxl_sample_car_bilinear_pairs_f64
+        with torch.cuda.device(sky.device):
+            _lib.check(fn(_wcs_ref(pairs.wcs), _lib.shape_arr((pairs.shape[0], pairs.shape[1], pairs.nc)), _ptr(pairs.data),
+                          pairs.src_rows[0], pairs.src_rows[1], sky.shape[0], _ptr(sky), _ptr(out), _stream(sky)))
+        return out
     data = _dev_map(m.data, "map data")
     _require_car(m.wcs)
     shape = m.shape if full_shape is None else tuple(full_shape)
     nc = data.shape[0] if data.dim() == 3 else 1
     row0, nrows = (0, shape[1]) if src_rows is None else src_rows
     out = torch.empty((nc, sky.shape[0]), dtype=data.dtype, device=sky.device)
-    lib = _lib.load()
     fn = lib.pxl_sample_car_bilinear_f32 if data.dtype == torch.float32 else lib.pxl_sample_car_bilinear_f64
     with torch.cuda.device(sky.device):
         _lib.check(fn(

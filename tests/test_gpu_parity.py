@@ -728,3 +728,42 @@ def test_unwind_inplace_and_overlap(pj, O, dev):
     big = torch.zeros((n + 8, 2), dtype=torch.float64, device=dev)
     with pytest.raises(RuntimeError):
         pj.pix2sky_(g, big[:n], big[8:], safe=True)
+
+
+def test_sample_row_pair_layout(pj, O, dev):
+    """The row-pair copy of a map (two adjacent entries hold a point's whole 2x2 neighbourhood) gives the same bits
+    as the direct gather and as the oracle: Float64 and Float32, full maps and declination strips, periodic and
+    partial-sky maps, points far outside and non-finite ones."""
+    rng = np.random.default_rng(99)
+    for name, (shape, wcs) in geoms(pj).items():
+        if shape[0] * shape[1] > 4_000_000:
+            continue
+        nx, ny = shape
+        n = 30011
+        sky = np.stack([2 * math.pi * rng.random(n) - math.pi, np.arcsin(2 * rng.random(n) - 1)], axis=1)
+        sky[:40, 0] += 4 * math.pi
+        sky[40] = (float("nan"), 0.1)
+        sky[41] = (0.2, float("inf"))
+        d_sky = to_dev(sky, dev)
+        for nc, f32, (r0, nr) in ((1, False, (0, ny)), (3, False, (ny // 4, ny // 2)), (2, True, (0, ny)), (1, True, (3, 5))):
+            src = rng.normal(size=(nc, nr, nx))
+            if f32:
+                src = src.astype(np.float32)
+                expect = O.sample_bilinear_f32(wcs, (nx, ny, nc), src, sky, src_row0=r0, src_nrows=nr)
+            else:
+                expect = O.sample_bilinear(wcs, (nx, ny, nc), src, sky, src_row0=r0, src_nrows=nr)
+            t = torch.from_numpy(src).to(dev)
+            m = pj.Enmap(t if nc > 1 else t[0], wcs)
+            pairs = pj.SamplePairs(m, src_rows=(r0, nr), full_shape=(nx, ny, nc))
+            got = pj.sample_bilinear(None, d_sky, pairs=pairs).cpu().numpy()
+            direct = pj.sample_bilinear(m, d_sky, src_rows=(r0, nr), full_shape=(nx, ny, nc)).cpu().numpy()
+            if f32:
+                assert _f32_equal(np.nan_to_num(got), np.nan_to_num(expect)) and _f32_equal(np.nan_to_num(got), np.nan_to_num(direct)), (name, nc, r0, nr)
+            else:
+                assert bits_equal(got, expect) and bits_equal(got, direct), (name, nc, r0, nr)
+            assert np.array_equal(np.isnan(got), np.isnan(expect))
+    # the pair buffer is caller-owned: wrong sizes are refused
+    shape, wcs = pj.fullsky_geometry(1 * DEG)
+    m = pj.Enmap(torch.zeros((shape[1], shape[0]), dtype=torch.float64, device=dev), wcs)
+    with pytest.raises(ValueError):
+        pj.SamplePairs(m, out=torch.empty(10, dtype=torch.float64, device=dev))

@@ -322,8 +322,12 @@ def fuzz_sample(rng):
     else:
         expect = O.sample_bilinear(wcs, (nx, ny, nc), src, sky, src_row0=s0, src_nrows=sn)
     m = pj.Enmap(to_dev(src, np.float32 if f32 else np.float64), wcs)
-    got = pj.sample_bilinear(m, to_dev(sky), src_rows=(s0, sn), full_shape=(nx, ny, nc)).cpu().numpy()
+    d_sky = to_dev(sky)
+    got = pj.sample_bilinear(m, d_sky, src_rows=(s0, sn), full_shape=(nx, ny, nc)).cpu().numpy()
     assert bits_equal(got, expect), ("sample", params)
+    pairs = pj.SamplePairs(m, src_rows=(s0, sn), full_shape=(nx, ny, nc))
+    got = pj.sample_bilinear(None, d_sky, pairs=pairs).cpu().numpy()
+    assert bits_equal(got, expect), ("sample via row pairs", params)
     return "sample_f32" if f32 else "sample_f64"
 
 
