@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -131,6 +132,28 @@ struct UnwindWs {
 };
 
 
+// The scratch comes from a library-owned stream-ordered pool that keeps what it has been given: with the default
+// pool (release threshold 0) every call on a drained stream went back to the driver for its memory (~250 us).
+static hipMemPool_t unwind_pool() {
+    static std::mutex mu;
+    static hipMemPool_t pools[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!pools[dev]) {
+        hipMemPoolProps props = {};
+        props.allocType = hipMemAllocationTypePinned;
+        props.location.type = hipMemLocationTypeDevice;
+        props.location.id = dev;
+        hipMemPool_t p = nullptr;
+        if (hipMemPoolCreate(&p, &props) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        uint64_t keep = ~0ull;
+        (void)hipMemPoolSetAttribute(p, hipMemPoolAttrReleaseThreshold, &keep);
+        pools[dev] = p;
+    }
+    return pools[dev];
+}
+
 static int unwind_ws_alloc(int64_t n, int nrow, hipStream_t st, UnwindWs* w) {
     w->nb = (n + PXL_SCAN_BLOCK - 1) / PXL_SCAN_BLOCK;
     // wave chunks of 64*U points: long enough to amortise the per-chunk work, short enough to fill the GPU
@@ -145,7 +168,9 @@ static int unwind_ws_alloc(int64_t n, int nrow, hipStream_t st, UnwindWs* w) {
     const size_t bytes_ws = up((size_t)w->nw * sizeof(int2)), bytes_wp = up((size_t)w->nw * sizeof(double2));
     const size_t total = bytes_c + bytes_r + 2 * bytes_b + bytes_ws + bytes_wp + 256;
     w->base = nullptr;
-    HIP_TRY(hipMallocAsync((void**)&w->base, total, st));
+    hipMemPool_t pool = unwind_pool();
+    if (pool) HIP_TRY(hipMallocFromPoolAsync((void**)&w->base, total, pool, st));
+    else HIP_TRY(hipMallocAsync((void**)&w->base, total, st));
     char* p = w->base;
     w->c = (int8_t*)p; p += bytes_c;
     w->rloc = (int32_t*)p; p += bytes_r;
@@ -216,7 +241,6 @@ static int unwind_multipass(int64_t n, int nrow, double* sky, double period, dou
     return rc;
 }
 
-static const int64_t kUnwindSerialMax = 4096;      // tiny batches: the exact serial kernel is already fast enough
 
 extern "C" {
 
@@ -250,13 +274,15 @@ int pxl_pix2sky_car_f64(const pxl_car_wcs* wcs, int64_t n, const double* pix, do
     CarAffine c = car_affine(*wcs);
     const int mode = wrap_mode == PXL_WRAP_REWIND ? 1 : (wrap_mode == PXL_WRAP_UNWIND ? 2 : 0);
     const dim3 pgrid(stream_grid((n + PXL_UNR - 1) / PXL_UNR, 256));
-    if (wrap_mode != PXL_WRAP_UNWIND || n <= kUnwindSerialMax) {
+    if (wrap_mode != PXL_WRAP_UNWIND) {
         hipLaunchKernelGGL(k_pix2sky_pairs, pgrid, dim3(256), 0, st, c, n, (const double2*)pix, (double2*)sky, mode,
                            (const int32_t*)nullptr);
-        int rc = check_launch("k_pix2sky_pairs");
-        if (rc || wrap_mode != PXL_WRAP_UNWIND) return rc;
-        hipLaunchKernelGGL(k_unwind_rows, dim3(2), dim3(64), 0, st, n, 2, sky, PXL_TWOPI_D, 0.0, 1, (const int32_t*)nullptr);
-        return check_launch("k_unwind_rows");
+        return check_launch("k_pix2sky_pairs");
+    }
+    if (n <= PXL_UWB_MAX) {       // small batch: everything in one launch of one block
+        UwSrcPix2 src{c, (const double2*)pix, PXL_TWOPI_D, 0.0, 1.0 / PXL_TWOPI_D};
+        hipLaunchKernelGGL((k_unwind_block<UwSrcPix2>), dim3(1), dim3(1024), 0, st, src, (double2*)sky, n);
+        return check_launch("k_unwind_block");
     }
     // safe=true on a long batch: fused rewind + verified scan; the multi-pass form only if its check fails
     const uintptr_t pa = (uintptr_t)pix, sa = (uintptr_t)sky, bytes = (uintptr_t)n * 16;
@@ -292,9 +318,15 @@ int pxl_unwind_f64(double* a, int64_t n, int nrow, double period, double ref_ang
     if (n == 0) return PXL_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 rgrid(stream_grid(((int64_t)nrow * n + 3) / 4, 256));
-    if (n <= kUnwindSerialMax) {
-        hipLaunchKernelGGL(k_unwind_rows, dim3(nrow), dim3(64), 0, st, n, nrow, a, period, ref_angle, 0, (const int32_t*)nullptr);
-        return check_launch("k_unwind_rows");
+    if (n <= PXL_UWB_MAX) {
+        if (nrow == 2) {
+            UwSrcAng2 src{(const double2*)a, period, ref_angle, 1.0 / period};
+            hipLaunchKernelGGL((k_unwind_block<UwSrcAng2>), dim3(1), dim3(1024), 0, st, src, (double2*)a, n);
+        } else {
+            UwSrcAng1 src{(const double*)a, period, ref_angle, 1.0 / period};
+            hipLaunchKernelGGL((k_unwind_block<UwSrcAng1>), dim3(1), dim3(1024), 0, st, src, a, n);
+        }
+        return check_launch("k_unwind_block");
     }
     UnwindWs w;
     int rc = unwind_ws_alloc(n, nrow, st, &w);

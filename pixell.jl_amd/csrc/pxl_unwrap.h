@@ -239,6 +239,8 @@ __device__ inline int uw_scan64(int v) {                   // inclusive sum over
     return v;
 }
 
+__device__ inline int uw_wave_total(int v) { return __builtin_amdgcn_readlane(uw_scan64(v), 63); }
+
 // m, the m of the element before (mp) and the nominal increment c of this lane's element.  The increment is only a
 // guess (a multiply by ~1/P instead of the reference's division): k_unwind_apply checks every element with the
 // reference's own formula, and both kernels form the guess identically.
@@ -397,6 +399,150 @@ __global__ __launch_bounds__(64) void k_unwind_apply(SRC src, typename SRC::raw_
         }
     }
     if (__any(bad) && lane == 0) atomicOr(flag, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small batches: the whole of unwind! in ONE launch of one 1024-thread block, no scratch, no follow-up launches
+// (a catalogue of a few thousand positions is launch-bound: the multi-kernel form costs ~60 us of dispatches, the
+// serial kernel 94 ns per point; one CU needs ~9 us per 4096-point round and pass, so this wins up to 8192 points).  The block sweeps rounds of 16 wave chunks of 64*PXL_UWB_U points; chunk sums,
+// NaN flags and the carries between rounds live in LDS, m stays in registers between the sum and the scan.  The
+// sweep runs twice: first verifying only, then -- if every element agreed with the reference recurrence -- storing;
+// otherwise waves 0/1 run the exact serial recurrence on the untouched input.
+// ------------------------------------------------------------------------------------------------
+#define PXL_UWB_U 4
+#define PXL_UWB_MAX 8192
+
+template <class SRC>
+__global__ __launch_bounds__(1024) void k_unwind_block(SRC src, typename SRC::raw_t* out, int64_t n) {
+    constexpr int NROW = SRC::NROW;
+    constexpr int U = PXL_UWB_U;
+    __shared__ int wsum[2][16], wnan[2][16];
+    __shared__ double wlast[2][16];
+    __shared__ double mcarry[2];
+    __shared__ int rcarry[2], pcarry[2], bad_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double P = src.period, rP = src.rperiod, ref = src.ref;
+    if (threadIdx.x == 0) bad_s = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (threadIdx.x == 0) { rcarry[0] = rcarry[1] = 0; pcarry[0] = pcarry[1] = 0; mcarry[0] = mcarry[1] = 0.0; }
+        __syncthreads();
+        if (pass == 1 && bad_s) break;
+        bool bad = false;
+        for (int64_t r0 = 0; r0 < n; r0 += 1024 * U) {
+            const int64_t base = r0 + (int64_t)wave * 64 * U;
+            // the m just before this chunk: inside a round the input has not been overwritten yet (reload it); across
+            // rounds it may have been (in-place calls), so wave 0 takes it from the previous round's last chunk
+            double mfirst[2] = {mcarry[0], mcarry[1]};
+            if (wave > 0) src.to_m((base >= 1 && base - 1 < n) ? src.load(base - 1) : src.zero(), mfirst);
+            double mlast[2] = {mfirst[0], mfirst[1]};
+            typename SRC::raw_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t k = base + (int64_t)u * 64 + lane;
+                v[u] = (k < n) ? src.load(k) : src.zero();
+            }
+            double m[U][2];
+            int cc[U][2];
+            int sum[2] = {0, 0};
+            bool nanl[2] = {false, false};
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t k = base + (int64_t)u * 64 + lane;
+                double mp[2];
+                cc[u][0] = cc[u][1] = 0;
+                uw_element(src, lane, k, k < n, v[u], mlast, m[u], mp, cc[u]);
+#pragma unroll
+                for (int r = 0; r < NROW; ++r) {
+                    sum[r] += cc[u][r];
+                    nanl[r] = nanl[r] || (k < n && m[u][r] != m[u][r]);
+                    mlast[r] = uw_lane63(m[u][r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NROW; ++r) {
+                const int tot = uw_wave_total(sum[r]);
+                const bool anynan = __ballot(nanl[r]) != 0ull;
+                if (lane == 0) { wsum[r][wave] = tot; wnan[r][wave] = anynan; wlast[r][wave] = mlast[r]; }
+            }
+            __syncthreads();
+            int carry[2];
+            bool pex[2];
+#pragma unroll
+            for (int r = 0; r < NROW; ++r) {
+                carry[r] = rcarry[r];
+                pex[r] = pcarry[r] != 0;
+                for (int w = 0; w < wave; ++w) { carry[r] += wsum[r][w]; pex[r] = pex[r] || wnan[r][w] != 0; }
+            }
+            mlast[0] = mfirst[0]; mlast[1] = mfirst[1];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t k = base + (int64_t)u * 64 + lane;
+                const bool valid = k < n;
+                int s = (cc[u][0] + 1) | (NROW == 2 ? (cc[u][1] + 1) << 16 : 0);
+                s = uw_scan64(s);
+                const int tot = __builtin_amdgcn_readlane(s, 63);
+                double y[2];
+#pragma unroll
+                for (int r = 0; r < NROW; ++r) {
+                    const double up = uw_shr1(m[u][r]);
+                    const double mp = lane == 0 ? mlast[r] : up;
+                    mlast[r] = uw_lane63(m[u][r]);
+                    const int field = r == 0 ? (s & 0xffff) : (s >> 16);
+                    const int rr = carry[r] + field - (lane + 1);
+                    carry[r] += (r == 0 ? (tot & 0xffff) : (tot >> 16)) - 64;
+                    const unsigned long long nanmask = __ballot(valid && m[u][r] != m[u][r]);
+                    const bool poisoned = pex[r] || (nanmask & ((2ull << lane) - 1ull)) != 0ull;
+                    pex[r] = pex[r] || nanmask != 0ull;
+                    if (!valid) continue;
+                    if (poisoned) { y[r] = __builtin_nan("") + ref; continue; }
+                    if (k > 0) {
+                        const double yprev = mp - (double)(rr - cc[u][r]) * P;
+                        const double a = m[u][r] - yprev;
+                        const double qa = a * rP;
+                        if (!(fabs(qa - (double)rr) < 0.5 - (fabs(qa) + 1.0) * 1e-14)) {
+                            const double q = a / P;
+                            if (!(rint(q) == (double)rr)) bad = true;
+                        }
+                    }
+                    y[r] = (k > 0 ? m[u][r] - (double)rr * P : m[u][r]) + ref;
+                }
+                if (pass == 1 && valid) SRC::store(out, k, y);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int r = 0; r < NROW; ++r) {
+                    int t = rcarry[r], pz = pcarry[r];
+                    for (int w = 0; w < 16; ++w) { t += wsum[r][w]; pz |= wnan[r][w]; }
+                    rcarry[r] = t; pcarry[r] = pz; mcarry[r] = wlast[r][15];
+                }
+            }
+            __syncthreads();
+        }
+        if (__any(bad) && lane == 0) atomicOr(&bad_s, 1);
+        __syncthreads();
+    }
+    if (!bad_s || wave >= NROW) return;
+    // exact serial recurrence (the k_unwind_rows loop) on the untouched input: wave `row` owns coordinate row `row`
+    const int row = wave;
+    double prev = 0.0;
+    bool have_prev = false;
+    for (int64_t b0 = 0; b0 < n; b0 += 64) {
+        const int64_t k = b0 + lane;
+        double mm[2] = {0.0, 0.0};
+        if (k < n) src.to_m(src.load(k), mm);
+        const double mine = mm[row];
+        double y = mine;
+        const int cnt = (int)((n - b0) < 64 ? (n - b0) : 64);
+        for (int l = 0; l < cnt; ++l) {
+            const double ml = __shfl(mine, l, 64);
+            const double yl = have_prev ? ml - rint((ml - prev) / P) * P : ml;
+            prev = yl;
+            have_prev = true;
+            if (lane == l) y = yl;
+        }
+        if (k < n) reinterpret_cast<double*>(out)[NROW * k + row] = y + ref;
+    }
 }
 
 // Exact serial form (one wave per coordinate row, 64 dependent steps per 64 points): the fallback when the

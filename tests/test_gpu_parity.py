@@ -767,3 +767,42 @@ def test_sample_row_pair_layout(pj, O, dev):
     m = pj.Enmap(torch.zeros((shape[1], shape[0]), dtype=torch.float64, device=dev), wcs)
     with pytest.raises(ValueError):
         pj.SamplePairs(m, out=torch.empty(10, dtype=torch.float64, device=dev))
+
+
+def _same_bits_or_nan(a, b):
+    """Bit equality where both are numbers, NaN where either is (the payload of a NaN is not part of the contract)."""
+    a, b = np.asarray(a), np.asarray(b)
+    na, nb = np.isnan(a), np.isnan(b)
+    return a.shape == b.shape and np.array_equal(na, nb) and bits_equal(np.where(na, 0.0, a), np.where(nb, 0.0, b))
+
+
+@pytest.mark.parametrize("n", [2, 63, 64, 65, 4095, 4096, 4097, 8191, 8192, 8193, 32769, 70000])
+def test_unwind_small_batches_single_block(pj, O, dev, n):
+    """Batches up to 8192 points run in one launch of one block (rounds of 4096 points with LDS carries), longer
+    ones in the multi-kernel form: same bits either side of every boundary, out of place and in place, for smooth
+    walks, a wrap at every step, exact half-period ties (serial recurrence inside the block) and NaN/Inf."""
+    g = _identity_wcs(pj)
+    rng = np.random.default_rng(4000 + n)
+    k = np.arange(n, dtype=np.float64)
+    cases = {
+        "walk": np.cumsum(rng.normal(0, 1.5, (n, 2)), axis=0) + rng.uniform(-50, 50, 2),
+        "jumps": rng.uniform(-400, 400, (n, 2)),
+        "ties": np.stack([k * math.pi, -k * math.pi + 0.25], axis=1),
+    }
+    bad = rng.uniform(-20, 20, (n, 2))
+    bad[n // 2, 0] = float("nan")
+    bad[(2 * n) // 3, 1] = float("inf")
+    cases["nonfinite"] = bad
+    for name, a in cases.items():
+        exp = O.pix2sky(g[1], a, O.WRAP_UNWIND)
+        got = pj.pix2sky(g, to_dev(a, dev), safe=True).cpu().numpy()
+        assert _same_bits_or_nan(got, exp), (name, n, "out of place")
+        buf = to_dev(a, dev)
+        pj.pix2sky_(g, buf, buf, safe=True)
+        assert _same_bits_or_nan(buf.cpu().numpy(), exp), (name, n, "in place")
+        for period, ref in ((2 * math.pi, 0.0), (5.0, 1.25)):
+            col = a[:, 0].copy()
+            assert _same_bits_or_nan(pj.unwind_(to_dev(col, dev), period, ref).cpu().numpy(), O.unwind_row(col, period, ref)), (name, n, period)
+            two = pj.unwind_(to_dev(a, dev), period, ref).cpu().numpy()
+            exp2 = np.stack([O.unwind_row(a[:, 0].copy(), period, ref), O.unwind_row(a[:, 1].copy(), period, ref)], axis=1)
+            assert _same_bits_or_nan(two, exp2), (name, n, period, "2xN")
