@@ -110,7 +110,7 @@ def cpu_baseline_reproject(shape_in, wcs_in, shape_out, wcs_out, budget_s=12.0):
         O.set_threads(1)
         return nxo * nrows * nc / dt / 1e6
 
-    rows1 = min(max(8, int(2.0e8 / (nxo * nc))), nyo // 2)  # ~2e8 output values for the 1-core leg
+    rows1 = min(max(8, int(1.5e9 / (nxo * nc))), nyo // 2)  # ~1.5e9 output values (~10 s) for the 1-core leg
     v1 = run(rows1, 1)
     cores = min(O.max_threads(), os.cpu_count() or 1)
     rowsN = max(rows1, int(min(budget_s * v1 * 1e6 * cores * 0.5, 1.5e9) / (nxo * nc)))
