@@ -63,6 +63,9 @@ int         pxl_version(void);
 size_t      pxl_last_error(char* buf, size_t n);
 /* number of visible HIP devices, or a negative error */
 int         pxl_device_count(void);
+/* unwind (safe=true on 2xN batches) takes its scratch (10 bytes per coordinate) from a library-owned stream-ordered
+ * pool on the current device and keeps it between calls; this returns the unused part to the driver */
+int         pxl_release_scratch(void);
 
 /* ---- pix2sky!(shape, wcs::AbstractCARWCS, pixcoords::2xN, skycoords::2xN; safe)   car_proj.jl:92-115
  *      In-place (pix == sky) is allowed; partially overlapping buffers are refused (PXL_EINVAL) in _UNWIND mode.

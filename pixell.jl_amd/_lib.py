@@ -36,6 +36,7 @@ SIGNATURES = {
     "pxl_version": (C.c_int, []),
     "pxl_last_error": (C.c_size_t, [C.c_char_p, C.c_size_t]),
     "pxl_device_count": (C.c_int, []),
+    "pxl_release_scratch": (C.c_int, []),
     "pxl_pix2sky_car_f64": (C.c_int, [_WP, _I64, _P, _P, C.c_int, _P]),
     "pxl_rewind_f64": (C.c_int, [_P, _I64, C.c_double, C.c_double, _P]),
     "pxl_unwind_f64": (C.c_int, [_P, _I64, C.c_int, C.c_double, C.c_double, _P]),

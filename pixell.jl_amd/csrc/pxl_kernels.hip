@@ -134,9 +134,11 @@ struct UnwindWs {
 
 // The scratch comes from a library-owned stream-ordered pool that keeps what it has been given: with the default
 // pool (release threshold 0) every call on a drained stream went back to the driver for its memory (~250 us).
+static std::mutex g_pool_mu;
+static hipMemPool_t g_pools[64] = {};
 static hipMemPool_t unwind_pool() {
-    static std::mutex mu;
-    static hipMemPool_t pools[64] = {};
+    std::mutex& mu = g_pool_mu;
+    hipMemPool_t* pools = g_pools;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
@@ -254,6 +256,14 @@ size_t pxl_last_error(char* buf, size_t n) {
         buf[m] = 0;
     }
     return len;
+}
+
+int pxl_release_scratch(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(PXL_ENODEV, "release_scratch: no current device");
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    if (g_pools[dev] && hipMemPoolTrimTo(g_pools[dev], 0) != hipSuccess) return fail(PXL_EHIP, "release_scratch: hipMemPoolTrimTo failed");
+    return PXL_OK;
 }
 
 int pxl_device_count(void) {

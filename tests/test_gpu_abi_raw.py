@@ -149,3 +149,18 @@ def test_concurrent_host_threads_and_streams(env, O):
     assert not errors, errors
     for k, case in enumerate(cases):
         assert bits_equal(results[k], case[5]), k
+
+
+def test_scratch_pool_is_kept_and_released(env):
+    """unwind scratch comes from a library-owned pool that survives between calls; pxl_release_scratch hands it back."""
+    pj, lib, dev = env
+    n = 2_000_000
+    g = ((10, 10), pj.CarClenshawCurtis((1.0, 1.0), (0.0, 0.0), (0.0, 0.0), 1.0))
+    pix = torch.rand((n, 2), dtype=torch.float64, device=dev) * 40 - 20
+    first = pj.pix2sky(g, pix, safe=True)
+    torch.cuda.synchronize()
+    assert lib.pxl_release_scratch() == 0
+    again = pj.pix2sky(g, pix, safe=True)           # the pool re-grows on demand
+    assert torch.equal(first, again)
+    torch.cuda.synchronize()
+    assert lib.pxl_release_scratch() == 0
