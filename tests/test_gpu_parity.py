@@ -806,3 +806,46 @@ def test_unwind_small_batches_single_block(pj, O, dev, n):
             two = pj.unwind_(to_dev(a, dev), period, ref).cpu().numpy()
             exp2 = np.stack([O.unwind_row(a[:, 0].copy(), period, ref), O.unwind_row(a[:, 1].copy(), period, ref)], axis=1)
             assert _same_bits_or_nan(two, exp2), (name, n, period, "2xN")
+
+
+def test_gnomonic_pix2sky_arrays_on_device(pj, O, dev, literals):
+    """pix2sky on device arrays of a Gnomonic map (pxl_pix2sky_tan_f64): against the oracle and as the inverse of
+    the device sky2pix."""
+    g = literals["gnomonic"]
+    wcs = pj.Gnomonic(g["cdelt"], g["crpix"], g["crval"])
+    shape = tuple(g["shape"])
+    rng = np.random.default_rng(17)
+    ip, jp = rng.uniform(1, shape[0], 40001), rng.uniform(1, shape[1], 40001)
+    ra, dec = pj.pix2sky((shape, wcs), to_dev(ip, dev), to_dev(jp, dev))
+    era, edec = O.pix2sky_tan(wcs, ip, jp)
+    assert np.abs(ra.cpu().numpy() - era).max() < 1e-12 and np.abs(dec.cpu().numpy() - edec).max() < 1e-12
+    x, y = pj.sky2pix((shape, wcs), ra, dec)
+    assert np.abs(x.cpu().numpy() - ip).max() < 1e-6 and np.abs(y.cpu().numpy() - jp).max() < 1e-6
+
+
+@pytest.mark.parametrize("f32", [False, True])
+def test_reproject_every_tile_shape(pj, O, dev, f32, monkeypatch):
+    """The LDS-DMA kernel is instantiated per (storage type, lane width, 16-byte chunks per source-row segment):
+    sweep lane widths x scale factors so that every instantiation the plan can pick runs against the oracle
+    (tools/fuzz_parity.py reaches them at random; this makes it deterministic)."""
+    rng = np.random.default_rng(321)
+    nx_in, ny_in = 3072, 24
+    wcs_in = pj.CarClenshawCurtis((-360.0 / nx_in, 2.0), (nx_in / 2 + 0.5, 12.0), (0.3, 0.0))
+    src = rng.normal(size=(2, ny_in, nx_in))
+    src = src.astype(np.float32) if f32 else src
+    d_src = torch.from_numpy(src).to(dev)
+    for pairs in (1, 2, 4):
+        monkeypatch.setenv("PXL_REPROJECT_PAIRS", str(pairs))
+        for sx in (0.2, 0.45, 0.7, 0.95, 1.2, 1.45, 1.9, 2.4, 2.9, 3.4, 3.9, 4.4, 4.9):
+            nxo = max(64, int(round(nx_in / sx)) & ~1)
+            wcs_out = pj.CarClenshawCurtis((-360.0 / nxo, 2.0 * rng.uniform(0.9, 1.1)), (nxo / 2 + 0.25, 12.3), (0.3, 0.0))
+            shape_out = (nxo, 20)
+            plan = pj.ReprojectPlan((nx_in, ny_in, 2), wcs_in, shape_out, wcs_out, device=dev)
+            dst = torch.full(plan.dst_tensor_shape(), float("nan"), dtype=d_src.dtype, device=dev)
+            plan.execute(d_src, dst)
+            got = dst.cpu().numpy()
+            if f32:
+                assert _f32_equal(got, O.reproject_f32(wcs_in, (nx_in, ny_in, 2), src, wcs_out, shape_out)), (pairs, sx)
+            else:
+                assert bits_equal(got, O.reproject(wcs_in, (nx_in, ny_in, 2), src, wcs_out, shape_out)), (pairs, sx)
+            plan.close()
