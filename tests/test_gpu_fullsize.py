@@ -130,6 +130,10 @@ def test_config5_scattered_sample_properties(pj, O, dev):
     rows = m.data[11999:12041].cpu().numpy()[None]
     exp = O.sample_bilinear(wcs, (nx, ny, 1), rows, sky[idx].cpu().numpy(), src_row0=11999, src_nrows=42)
     assert bits_equal(out[:, idx].cpu().numpy(), exp)
+    # the row-pair copy of the same map (15 GB: offsets beyond 2^31 bytes) gives the same bits for every point
+    pairs = pj.SamplePairs(m)
+    assert torch.equal(pj.sample_bilinear(None, sky, pairs=pairs), out)
+    del pairs
     m.data.fill_(3.25)
     assert float((pj.sample_bilinear(m, sky) - 3.25).abs().max()) < 1e-12
 
