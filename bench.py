@@ -187,6 +187,12 @@ def main():
                          "the N-rank flow on a box with fewer GPUs than ranks (with PXL_BENCH_SHARE_GPU=1)")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: libraries (RCCL prints a version banner, gloo its connection notes) write
+    # to file descriptor 1 behind Python's back, so everything else is sent to stderr from here on
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -204,7 +210,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+            # eager communicator setup on the rank's own device; lazy when ranks share a GPU for a rehearsal (RCCL then
+            # refuses the duplicate device at the first exchange, which exercises the transport fallback below)
+            share = bool(os.environ.get("PXL_BENCH_SHARE_GPU"))
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=None if share else dev)
         else:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
@@ -213,42 +222,76 @@ def main():
     else:
         result = bench_reproject(args, rank, world, dev)
     if rank == 0:
-        print(json.dumps(result))
+        json_out.write(json.dumps(result) + "\n")
+        json_out.flush()
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=_CTRL)
         dist.destroy_process_group()
+
+
+_CTRL = None        # gloo control group, set when the RCCL transport failed and the run fell back to gloo
+
+
+def _on_host():
+    """Collectives of the measurement harness run on the host when the job's backend is gloo (rehearsal or fallback)."""
+    return _CTRL is not None or dist.get_backend() != "nccl"
 
 
 def timed_region(world, dev, steps, body):
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=_CTRL)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for k in range(steps):
         body(k)
     torch.cuda.synchronize(dev)
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=_CTRL)
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if _on_host() else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_CTRL)
         dt = float(t.item())
     return dt
 
 
 def bench_reproject(args, rank, world, dev):
+    global _CTRL
     shape_in, wcs_in, shape_out, wcs_out, desc = workload_geometry(args.workload)
     nx, ny, nc = shape_in
     nxo, nyo = shape_out
     sh = pj.DecStripReprojector(shape_in, wcs_in, shape_out, wcs_out, rank, world, dev)
     src, dst, placement = place_buffers(sh, args.placements, dev)
     torch.cuda.synchronize(dev)
+    transport = "RCCL"
     if world > 1:
-        # prime the RCCL point-to-point connections (communicator setup is not part of any step)
-        sh.step(src, dst)
-        torch.cuda.synchronize(dev)
-        dist.barrier()
+        # prime the RCCL point-to-point connections (communicator setup is not part of any step).  If RCCL raises
+        # here on any rank (IPC / P2P not usable on this node), every rank switches the halo to the host-staged gloo
+        # transport so the run still measures the sharded operator; the JSON line says which transport ran.
+        if dist.get_backend() == "nccl":
+            ctrl = dist.new_group(backend="gloo")
+            err = ""
+            try:
+                sh.step(src, dst)
+                torch.cuda.synchronize(dev)
+            except Exception as e:                      # noqa: BLE001 -- reported below, never swallowed
+                err = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200])
+            failed = torch.tensor([1 if err else 0], dtype=torch.int32)
+            dist.all_reduce(failed, op=dist.ReduceOp.MAX, group=ctrl)
+            if int(failed.item()):
+                print("bench.py rank %d: RCCL halo exchange failed (%s); falling back to host-staged gloo" % (rank, err or "on another rank"),
+                      file=sys.stderr, flush=True)
+                sh.group, sh._staging = ctrl, None
+                _CTRL = ctrl
+                transport = "gloo host-staged FALLBACK (RCCL send/recv raised: %s)" % (err or "on another rank")
+                sh.step(src, dst)
+                torch.cuda.synchronize(dev)
+            dist.barrier(group=ctrl)
+        else:
+            transport = "gloo (host-staged REHEARSAL)"
+            sh.step(src, dst)
+            torch.cuda.synchronize(dev)
+            dist.barrier()
 
     for _ in range(args.warmup):
         sh.step(src, dst)
@@ -284,7 +327,7 @@ def bench_reproject(args, rank, world, dev):
         "config": {"workload": desc, "shape_in": list(shape_in), "shape_out": list(shape_out) + [nc],
                    "parallelism": "dec-strip x%d, %d-row halo via %s send/recv" % (
                        world, max([hi - lo for _, lo, hi in sh.recvs + sh.sends], default=0),
-                       "RCCL" if (world == 1 or dist.get_backend() == "nccl") else "gloo (host-staged REHEARSAL)"),
+                       transport),
                    "halo_bytes_per_message": max([(hi - lo) * nx * nc * 8 for _, lo, hi in sh.recvs + sh.sends], default=0),
                    "bytes_per_output_value": round(8.0 * (nx * ny + nxo * nyo) / (nxo * nyo), 3),
                    "buffer_placement": placement},
@@ -301,9 +344,9 @@ def bench_reproject(args, rank, world, dev):
         # worst case is reported
         chk = spot_check(sh, src, dst, shape_in, wcs_in, shape_out, wcs_out)
         if world > 1:
-            on = dev if dist.get_backend() == "nccl" else "cpu"
-            t = torch.tensor([chk["max_abs_err"], 0.0 if chk["bit_identical"] else 1.0], dtype=torch.float64, device=on)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t = torch.tensor([chk["max_abs_err"], 0.0 if chk["bit_identical"] else 1.0], dtype=torch.float64,
+                             device="cpu" if _on_host() else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_CTRL)
             chk = {"max_abs_err": float(t[0]), "bit_identical": bool(t[1] == 0.0), "ranks_checked": world}
         result["check"] = chk
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
