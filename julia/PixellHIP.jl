@@ -8,7 +8,8 @@
 module PixellHIP
 
 using Pixell
-import Pixell: Enmap, AbstractCARWCS, CarClenshawCurtis, getwcs, pix2sky, pix2sky!, sky2pix, sky2pix!, posmap
+import Pixell: Enmap, AbstractCARWCS, CarClenshawCurtis, getwcs, pix2sky, pix2sky!, sky2pix, sky2pix!, posmap,
+               pixareamap!, rewind!, unwind!
 
 const libpixell_hip = get(ENV, "PIXELL_HIP_LIB", "libpixell_hip.so")
 const libhip = "libamdhip64.so"
@@ -106,5 +107,74 @@ function reproject(m::Enmap{Float64,N,<:HIPArray,<:AbstractCARWCS}, shape_out::T
     return Enmap(out, wcs_out)
 end
 
-export HIPArray, posmap_device, reproject
+# ---- a kept reprojection plan (coordinate tables live on the device): create once, execute per map.
+#      Float64 and Float32 storage; windows (row0, nrows) describe declination strips of a sharded map.
+mutable struct ReprojectPlan
+    handle::Ptr{Cvoid}
+    shape_in::NTuple{3,Int}
+    shape_out::NTuple{2,Int}
+    function ReprojectPlan(shape_in, wcs_in::AbstractCARWCS, shape_out, wcs_out::AbstractCARWCS;
+                           src_rows=(0, shape_in[2]), dst_rows=(0, shape_out[2]))
+        nc = length(shape_in) > 2 ? shape_in[3] : 1
+        shp_in, shp_out = Int64[shape_in[1], shape_in[2], nc], Int64[shape_out[1], shape_out[2]]
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        GC.@preserve shp_in shp_out check(ccall((:pxl_reproject_plan_create, libpixell_hip), Cint,
+            (Ref{CarWCS}, Ptr{Int64}, Int64, Int64, Ref{CarWCS}, Ptr{Int64}, Int64, Int64, Ptr{Ptr{Cvoid}}),
+            CarWCS(wcs_in), shp_in, src_rows[1], src_rows[2], CarWCS(wcs_out), shp_out, dst_rows[1], dst_rows[2], h))
+        p = new(h[], (shape_in[1], shape_in[2], nc), (shape_out[1], shape_out[2]))
+        finalizer(x -> ccall((:pxl_reproject_plan_destroy, libpixell_hip), Cint, (Ptr{Cvoid},), x.handle), p)
+    end
+end
+
+function reproject!(dst::HIPArray{Float64}, plan::ReprojectPlan, src::HIPArray{Float64})
+    GC.@preserve src dst check(ccall((:pxl_reproject_execute, libpixell_hip), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cvoid}), plan.handle, src.ptr, dst.ptr, NULLSTREAM))
+    return dst
+end
+function reproject!(dst::HIPArray{Float32}, plan::ReprojectPlan, src::HIPArray{Float32})
+    GC.@preserve src dst check(ccall((:pxl_reproject_execute_f32, libpixell_hip), Cint,
+        (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cvoid}), plan.handle, src.ptr, dst.ptr, NULLSTREAM))
+    return dst
+end
+
+# ---- scattered bilinear sample at a 2xN device batch of (ra, dec): one value per point and component
+function sample_bilinear(m::Enmap{Float64,N,<:HIPArray,<:AbstractCARWCS}, sky::DevCoords) where {N}
+    nc = N == 3 ? size(m, 3) : 1
+    n = size(sky, 2)
+    out = HIPArray{Float64}(undef, n, nc)                    # (n, nc) column-major, as the header says
+    shp = Int64[size(m, 1), size(m, 2), nc]
+    src = parent(m)
+    GC.@preserve src sky out shp check(ccall((:pxl_sample_car_bilinear_f64, libpixell_hip), Cint,
+        (Ref{CarWCS}, Ptr{Int64}, Ptr{Cdouble}, Int64, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cvoid}),
+        CarWCS(getwcs(m)), shp, src.ptr, 0, size(m, 2), n, sky.ptr, out.ptr, NULLSTREAM))
+    return out
+end
+
+# ---- pixareamap! (enmap_ops.jl:124-138) and unwind! / rewind! (enmap_ops.jl:15-32) on device arrays
+function Pixell.pixareamap!(pixareas::Enmap{Float64,2,<:HIPArray,<:AbstractCARWCS})
+    shp = Int64[size(pixareas, 1), size(pixareas, 2)]
+    a = parent(pixareas)
+    GC.@preserve a shp check(ccall((:pxl_pixareamap_car_f64, libpixell_hip), Cint,
+        (Ref{CarWCS}, Ptr{Int64}, Int64, Int64, Ptr{Cdouble}, Ptr{Cvoid}),
+        CarWCS(getwcs(pixareas)), shp, 0, size(pixareas, 2), a.ptr, NULLSTREAM))
+    return pixareas
+end
+
+function Pixell.rewind!(angles::HIPArray{Float64}; period=2π, ref_angle=0.0)
+    GC.@preserve angles check(ccall((:pxl_rewind_f64, libpixell_hip), Cint,
+        (Ptr{Cdouble}, Int64, Cdouble, Cdouble, Ptr{Cvoid}), angles.ptr, length(angles), period, ref_angle, NULLSTREAM))
+    return angles
+end
+
+# dims = 2 on a 2xN batch (what pix2sky! uses, car_proj.jl:111) or a plain vector
+function Pixell.unwind!(angles::HIPArray{Float64,N}; dims=N, period=2π, ref_angle=0.0) where {N}
+    @assert (N == 1) || (N == 2 && size(angles, 1) == 2 && dims == 2) "device unwind! handles vectors and 2xN batches along N"
+    nrow = N == 1 ? 1 : 2
+    GC.@preserve angles check(ccall((:pxl_unwind_f64, libpixell_hip), Cint,
+        (Ptr{Cdouble}, Int64, Cint, Cdouble, Cdouble, Ptr{Cvoid}),
+        angles.ptr, N == 1 ? length(angles) : size(angles, 2), nrow, period, ref_angle, NULLSTREAM))
+    return angles
+end
+
+export HIPArray, posmap_device, reproject, reproject!, ReprojectPlan, sample_bilinear
 end # module

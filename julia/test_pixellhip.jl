@@ -56,3 +56,25 @@ end
     src = Array(parent(m))
     @test maximum(abs.(out .- 0.5 .* (src .+ circshift(src, (-1, 0))))) < 1e-12
 end
+
+@testset "kept plan, Float32 storage, sampler, pixareamap!, unwind!" begin
+    shape, wcs = fullsky_geometry(2π / 256)
+    shape2, wcs2 = fullsky_geometry(2π / 512)
+    plan = PixellHIP.ReprojectPlan(shape, wcs, shape2, wcs2)
+    src = randn(shape...)
+    out64 = Array(PixellHIP.reproject!(HIPArray{Float64}(undef, shape2...), plan, HIPArray(src)))
+    @test out64 == Array(parent(PixellHIP.reproject(Enmap(HIPArray(src), wcs), shape2, wcs2)))
+    out32 = Array(PixellHIP.reproject!(HIPArray{Float32}(undef, shape2...), plan, HIPArray(Float32.(src))))
+    @test maximum(abs.(out32 .- Float32.(out64))) < 1f-5
+    # sampling at the output pixel centres reproduces the reprojection (to rounding: two sky2pix roundings)
+    m = Enmap(HIPArray(src), wcs)
+    ra, dec = posmap(shape2, wcs2)
+    sky = HIPArray(permutedims(hcat(vec(parent(ra)), vec(parent(dec)))))
+    @test maximum(abs.(vec(Array(PixellHIP.sample_bilinear(m, sky))) .- vec(out64))) < 1e-9
+    # pixareamap! against the reference's CPU method (test_geometry.jl:287-316)
+    a_dev = Enmap(HIPArray{Float64}(undef, shape...), wcs)
+    @test maximum(abs.(Array(parent(pixareamap!(a_dev))) .- parent(pixareamap(Enmap(zeros(shape...), wcs))))) < 100eps()
+    # unwind! along the point axis of a 2xN batch (enmap_ops.jl:26-32), bit for bit
+    ang = cumsum(1.5 .* randn(2, 50_000), dims=2)
+    @test Array(unwind!(HIPArray(copy(ang)); dims=2)) == unwind!(copy(ang); dims=2)
+end
