@@ -129,7 +129,14 @@ struct UnwindWs {
     int2* wsum; double2* wprev;                                 // fused form: per wave chunk
     int64_t nb, nw;
     int U;                                                      // points per wave chunk / 64
+    bool multipass;                                             // per-element scratch of the multi-pass fallback present
 };
+
+// Batches up to this size fall back (half-period ties only) to ONE gated launch of the single-block form instead
+// of the ten gated launches of the multi-pass form: ~25 us less per call, where that is most of the call.  The
+// single block is slower when it does run (9 us per 4096 points and pass, then the serial recurrence), so longer
+// batches keep the multi-pass form, whose fixed cost no longer matters there.
+static const int64_t kUnwindBlockFallbackMax = 1LL << 22;
 
 
 // The scratch comes from a library-owned stream-ordered pool that keeps what it has been given: with the default
@@ -166,7 +173,9 @@ static int unwind_ws_alloc(int64_t n, int nrow, hipStream_t st, UnwindWs* w) {
     w->nw = (n + 64 * U - 1) / (64 * U);
     if (w->nb > 0x7fffffffLL || w->nw > 0x7fffffffLL || n > 0x7fffffffLL) return fail(PXL_EINVAL, "unwind: batch too long (2^31 points)");
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t bytes_c = up((size_t)nrow * n), bytes_r = up((size_t)4 * nrow * n), bytes_b = up((size_t)4 * nrow * w->nb);
+    w->multipass = n > kUnwindBlockFallbackMax;
+    const size_t bytes_c = w->multipass ? up((size_t)nrow * n) : 0, bytes_r = w->multipass ? up((size_t)4 * nrow * n) : 0,
+                 bytes_b = w->multipass ? up((size_t)4 * nrow * w->nb) : 0;
     const size_t bytes_ws = up((size_t)w->nw * sizeof(int2)), bytes_wp = up((size_t)w->nw * sizeof(double2));
     const size_t total = bytes_c + bytes_r + 2 * bytes_b + bytes_ws + bytes_wp + 256;
     w->base = nullptr;
@@ -182,7 +191,7 @@ static int unwind_ws_alloc(int64_t n, int nrow, hipStream_t st, UnwindWs* w) {
     w->wprev = (double2*)p; p += bytes_wp;
     w->flag = (int32_t*)p;
     w->firstnan = (unsigned long long*)(p + 16);
-    if (hipMemsetAsync(w->flag, 0, 16, st) != hipSuccess || hipMemsetAsync(w->firstnan, 0xFF, 16, st) != hipSuccess) {
+    if (hipMemsetAsync(w->flag, 0, 32, st) != hipSuccess) {      // flags and the (complemented) first-NaN indices
         (void)hipFreeAsync(w->base, st);
         return fail(PXL_EHIP, "unwind: hipMemsetAsync failed");
     }
@@ -291,7 +300,7 @@ int pxl_pix2sky_car_f64(const pxl_car_wcs* wcs, int64_t n, const double* pix, do
     }
     if (n <= PXL_UWB_MAX) {       // small batch: everything in one launch of one block
         UwSrcPix2 src{c, (const double2*)pix, PXL_TWOPI_D, 0.0, 1.0 / PXL_TWOPI_D};
-        hipLaunchKernelGGL((k_unwind_block<UwSrcPix2>), dim3(1), dim3(1024), 0, st, src, (double2*)sky, n);
+        hipLaunchKernelGGL((k_unwind_block<UwSrcPix2>), dim3(1), dim3(1024), 0, st, src, (double2*)sky, n, (const int32_t*)nullptr);
         return check_launch("k_unwind_block");
     }
     // safe=true on a long batch: fused rewind + verified scan; the multi-pass form only if its check fails
@@ -304,9 +313,14 @@ int pxl_pix2sky_car_f64(const pxl_car_wcs* wcs, int64_t n, const double* pix, do
     rc = unwind_fused(src, (double2*)sky, n, pa == sa, w, st);
     if (rc == PXL_OK) {
         const int32_t* failed = w.flag + 2;
-        hipLaunchKernelGGL(k_pix2sky_pairs, dim3(std::min(pgrid.x, 2048u)), dim3(256), 0, st, c, n, (const double2*)pix, (double2*)sky, 2, failed);
-        rc = check_launch("k_pix2sky_pairs");
-        if (rc == PXL_OK) rc = unwind_multipass(n, 2, sky, PXL_TWOPI_D, 0.0, w, failed, st);
+        if (!w.multipass) {
+            hipLaunchKernelGGL((k_unwind_block<UwSrcPix2>), dim3(1), dim3(1024), 0, st, src, (double2*)sky, n, failed);
+            rc = check_launch("k_unwind_block");
+        } else {
+            hipLaunchKernelGGL(k_pix2sky_pairs, dim3(std::min(pgrid.x, 2048u)), dim3(256), 0, st, c, n, (const double2*)pix, (double2*)sky, 2, failed);
+            rc = check_launch("k_pix2sky_pairs");
+            if (rc == PXL_OK) rc = unwind_multipass(n, 2, sky, PXL_TWOPI_D, 0.0, w, failed, st);
+        }
     }
     return unwind_ws_free(&w, st, rc);
 }
@@ -331,25 +345,30 @@ int pxl_unwind_f64(double* a, int64_t n, int nrow, double period, double ref_ang
     if (n <= PXL_UWB_MAX) {
         if (nrow == 2) {
             UwSrcAng2 src{(const double2*)a, period, ref_angle, 1.0 / period};
-            hipLaunchKernelGGL((k_unwind_block<UwSrcAng2>), dim3(1), dim3(1024), 0, st, src, (double2*)a, n);
+            hipLaunchKernelGGL((k_unwind_block<UwSrcAng2>), dim3(1), dim3(1024), 0, st, src, (double2*)a, n, (const int32_t*)nullptr);
         } else {
             UwSrcAng1 src{(const double*)a, period, ref_angle, 1.0 / period};
-            hipLaunchKernelGGL((k_unwind_block<UwSrcAng1>), dim3(1), dim3(1024), 0, st, src, a, n);
+            hipLaunchKernelGGL((k_unwind_block<UwSrcAng1>), dim3(1), dim3(1024), 0, st, src, a, n, (const int32_t*)nullptr);
         }
         return check_launch("k_unwind_block");
     }
     UnwindWs w;
     int rc = unwind_ws_alloc(n, nrow, st, &w);
     if (rc) return rc;
+    const int32_t* failed = w.flag + 2;
     if (nrow == 2) {
         UwSrcAng2 src{(const double2*)a, period, ref_angle, 1.0 / period};
         rc = unwind_fused(src, (double2*)a, n, true, w, st);
+        if (rc == PXL_OK && !w.multipass)
+            hipLaunchKernelGGL((k_unwind_block<UwSrcAng2>), dim3(1), dim3(1024), 0, st, src, (double2*)a, n, failed);
     } else {
         UwSrcAng1 src{(const double*)a, period, ref_angle, 1.0 / period};
         rc = unwind_fused(src, a, n, true, w, st);
+        if (rc == PXL_OK && !w.multipass)
+            hipLaunchKernelGGL((k_unwind_block<UwSrcAng1>), dim3(1), dim3(1024), 0, st, src, a, n, failed);
     }
-    if (rc == PXL_OK) {
-        const int32_t* failed = w.flag + 2;
+    if (rc == PXL_OK && !w.multipass) rc = check_launch("k_unwind_block");
+    if (rc == PXL_OK && w.multipass) {
         hipLaunchKernelGGL(k_rewind, dim3(std::min(rgrid.x, 2048u)), dim3(256), 0, st, (int64_t)nrow * n, a, period, ref_angle, 1, failed);
         rc = check_launch("k_rewind");
         if (rc == PXL_OK) rc = unwind_multipass(n, nrow, a, period, ref_angle, w, failed, st);

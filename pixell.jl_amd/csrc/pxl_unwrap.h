@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256) void k_unwrap_apply(int64_t n, int nrow, doubl
 // Fused fast path of unwind!: the same verified integer scan, but the rewound values m never touch memory.
 //   k_unwind_sums   reads the input once, forms m in registers, sums the nominal increments of each 64*U-point
 //                   wave chunk, remembers the m just before each chunk and the first NaN of each coordinate row
+//                   (as the maximum of ~index, so that zero-filled scratch means "none")
 //   k_scan_wsums    exclusive scan of the chunk sums (one block)
 //   k_unwind_apply  reads the input again, re-forms m and the increments, scans them inside the wave, checks every
 //                   element against the reference's floating-point recurrence and writes y = m - r*P + ref
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(64) void k_unwind_sums(SRC src, int64_t n, int U, i
         wsum[blockIdx.x] = make_int2(sum[0], sum[1]);
 #pragma unroll
         for (int r = 0; r < SRC::NROW; ++r)
-            if (nanat[r] != ~0ULL) atomicMin(&firstnan[r], nanat[r]);
+            if (nanat[r] != ~0ULL) atomicMax(&firstnan[r], ~nanat[r]);     // stored complemented: zero = no NaN
     }
 }
 
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(64) void k_unwind_apply(SRC src, typename SRC::raw_
     double mlast[2] = {wp.x, wp.y};
     const int2 w0 = woff[blockIdx.x];
     int carry[2] = {w0.x, w0.y};                       // r of the element just before this chunk
-    const unsigned long long fn[2] = {firstnan[0], firstnan[1]};
+    const unsigned long long fn[2] = {~firstnan[0], ~firstnan[1]};        // index of the first NaN of each row
     bool bad = false;
     for (int u0 = 0; u0 < U; u0 += PXL_UW_G) {
         typename SRC::raw_t v[PXL_UW_G];
@@ -413,17 +414,22 @@ __global__ __launch_bounds__(64) void k_unwind_apply(SRC src, typename SRC::raw_
 #define PXL_UWB_MAX 8192
 
 template <class SRC>
-__global__ __launch_bounds__(1024) void k_unwind_block(SRC src, typename SRC::raw_t* out, int64_t n) {
+__global__ __launch_bounds__(1024) void k_unwind_block(SRC src, typename SRC::raw_t* out, int64_t n,
+                                                       const int32_t* __restrict__ gate) {
+    // gate: as the fallback of the multi-kernel form this launch runs only if *gate != 0 (its check failed)
     constexpr int NROW = SRC::NROW;
     constexpr int U = PXL_UWB_U;
+    if (gate && *gate == 0) return;
     __shared__ int wsum[2][16], wnan[2][16];
     __shared__ double wlast[2][16];
     __shared__ double mcarry[2];
     __shared__ int rcarry[2], pcarry[2], bad_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double P = src.period, rP = src.rperiod, ref = src.ref;
-    if (threadIdx.x == 0) bad_s = 0;
-    for (int pass = 0; pass < 2; ++pass) {
+    // as a fallback the verification is already known to fail (same increments, same check): go straight to the
+    // serial recurrence
+    if (threadIdx.x == 0) bad_s = gate ? 1 : 0;
+    for (int pass = gate ? 2 : 0; pass < 2; ++pass) {
         if (threadIdx.x == 0) { rcarry[0] = rcarry[1] = 0; pcarry[0] = pcarry[1] = 0; mcarry[0] = mcarry[1] = 0.0; }
         __syncthreads();
         if (pass == 1 && bad_s) break;
@@ -522,6 +528,7 @@ __global__ __launch_bounds__(1024) void k_unwind_block(SRC src, typename SRC::ra
         if (__any(bad) && lane == 0) atomicOr(&bad_s, 1);
         __syncthreads();
     }
+    __syncthreads();
     if (!bad_s || wave >= NROW) return;
     // exact serial recurrence (the k_unwind_rows loop) on the untouched input: wave `row` owns coordinate row `row`
     const int row = wave;
