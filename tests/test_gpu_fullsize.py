@@ -158,3 +158,26 @@ def test_getindex_on_a_map_beyond_2GiB(pj, dev):
     assert float(big.data[12345, 23456]) == (ny - 1 - 12345) * nx + 23457
     s_expect = float(data[:, 1:-1].sum())
     assert abs(float(big.data.sum()) - s_expect) <= 1e-9 * abs(s_expect)
+
+
+def test_config4_float32_storage_fullsize(pj, dev):
+    """The config-4 geometry with Float32 maps (11.2 GB per map: plane offsets beyond 2^31 elements in the Float32
+    kernels too): the Float32 path must equal the Float64 path on the widened input, rounded once -- every value of
+    the 2.8e9-element output is compared."""
+    shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 43200, dims=(3,))
+    nx, ny, nc = shape_in
+    wcs_out = pj.CarClenshawCurtis(wcs_in.cdelt, (wcs_in.crpix[0] + 0.5, wcs_in.crpix[1] + 0.5), wcs_in.crval)
+    src64 = torch.empty((nc, ny, nx), dtype=torch.float64, device=dev)
+    pj.fill_random_(src64, 99)
+    src32 = src64.float()
+    src64.copy_(src32)                                   # the widened Float32 values, exactly
+    plan = pj.ReprojectPlan(shape_in, wcs_in, (nx, ny), wcs_out, device=dev)
+    dst32 = torch.empty((nc, ny, nx), dtype=torch.float32, device=dev)
+    plan.execute(src32, dst32)
+    del src32
+    dst64 = torch.empty((nc, ny, nx), dtype=torch.float64, device=dev)
+    plan.execute(src64, dst64)
+    del src64
+    for c in range(nc):                                  # plane by plane keeps the temporaries small
+        assert torch.equal(dst32[c], dst64[c].float()), c
+    plan.close()
