@@ -182,6 +182,9 @@ def main():
     ap.add_argument("--placements", type=int, default=int(os.environ.get("PXL_BENCH_PLACEMENTS", "4")),
                     help="buffer placements tried at setup (1 = take the first allocation)")
     ap.add_argument("--check", action="store_true", help="verify a sample of the output against the oracle")
+    ap.add_argument("--halo", default="auto", choices=["auto", "native", "torch", "gloo"],
+                    help="halo transport for N > 1 (auto: native RCCL step, then torch P2P, then host-staged gloo; each "
+                         "is primed and checked against the oracle before it is used)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path); gloo = host-staged halo, only for rehearsing "
                          "the N-rank flow on a box with fewer GPUs than ranks (with PXL_BENCH_SHARE_GPU=1)")
@@ -263,42 +266,70 @@ def bench_reproject(args, rank, world, dev):
     sh = pj.DecStripReprojector(shape_in, wcs_in, shape_out, wcs_out, rank, world, dev)
     src, dst, placement = place_buffers(sh, args.placements, dev)
     torch.cuda.synchronize(dev)
-    transport = "RCCL"
+    # ---- choose the halo transport (N > 1).  Candidates in order: "native" = the library's own sharded step (RCCL
+    # send/recv issued from C straight out of / into the resident buffer), "torch" = torch.distributed
+    # batch_isend_irecv over the same RCCL communicator with packed staging buffers, "gloo" = host-staged (rehearsals
+    # and last resort).  The development boxes have one GPU, so the RCCL transports first meet real peers in the
+    # driver's multi-GPU run: each candidate is primed (communicator setup is not part of any step) AND its result
+    # spot-checked against the oracle on every rank; if any rank raises or mismatches, all ranks agree over a gloo
+    # control group to move on to the next candidate.  The JSON line names the transport that ran.
+    transport, halo = "none (one rank)", "torch"
     if world > 1:
-        # prime the RCCL point-to-point connections (communicator setup is not part of any step).  If RCCL raises
-        # here on any rank (IPC / P2P not usable on this node), every rank switches the halo to the host-staged gloo
-        # transport so the run still measures the sharded operator; the JSON line says which transport ran.
-        if dist.get_backend() == "nccl":
+        wanted = {"auto": ["native", "torch", "gloo"], "native": ["native"], "torch": ["torch"], "gloo": ["gloo"]}[args.halo]
+        if dist.get_backend() != "nccl":
+            wanted, ctrl = ["gloo"], None
+        else:
             ctrl = dist.new_group(backend="gloo")
+        notes = []
+        chosen = None
+        for cand in wanted:
             err = ""
             try:
-                sh.step(src, dst)
+                if cand == "gloo" and ctrl is not None:
+                    sh.group, sh._staging = ctrl, None
+                dst.fill_(float("nan"))
+                (sh.step_native if cand == "native" else sh.step)(src, dst)
                 torch.cuda.synchronize(dev)
-            except Exception as e:                      # noqa: BLE001 -- reported below, never swallowed
-                err = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200])
+                chk = spot_check(sh, src, dst, shape_in, wcs_in, shape_out, wcs_out)
+                if not chk["bit_identical"]:
+                    err = "result differs from the oracle (max abs err %.3g)" % chk["max_abs_err"]
+            except Exception as e:                      # noqa: BLE001 -- reported, never swallowed
+                err = "%s: %s" % (type(e).__name__, (str(e).splitlines() or [""])[0][:200])
             failed = torch.tensor([1 if err else 0], dtype=torch.int32)
             dist.all_reduce(failed, op=dist.ReduceOp.MAX, group=ctrl)
-            if int(failed.item()):
-                print("bench.py rank %d: RCCL halo exchange failed (%s); falling back to host-staged gloo" % (rank, err or "on another rank"),
-                      file=sys.stderr, flush=True)
-                sh.group, sh._staging = ctrl, None
-                _CTRL = ctrl
-                transport = "gloo host-staged FALLBACK (RCCL send/recv raised: %s)" % (err or "on another rank")
-                sh.step(src, dst)
-                torch.cuda.synchronize(dev)
-            dist.barrier(group=ctrl)
+            if not int(failed.item()):
+                chosen = cand
+                break
+            notes.append("%s failed (%s)" % (cand, err or "on another rank"))
+            print("bench.py rank %d: halo transport %s" % (rank, notes[-1]), file=sys.stderr, flush=True)
+        if chosen is None:
+            sys.exit("bench.py: no halo transport worked: " + "; ".join(notes))
+        halo = chosen
+        if chosen == "gloo" and ctrl is not None:
+            _CTRL = ctrl                                 # the harness collectives move to the host as well
+        transport = {"native": "RCCL send/recv issued by pxl_reproject_sharded_step (no staging)",
+                     "torch": "RCCL via torch.distributed batch_isend_irecv (packed staging buffers)",
+                     "gloo": "gloo (host-staged %s)" % ("REHEARSAL" if ctrl is None else "FALLBACK")}[chosen]
+        if notes:
+            transport += "; " + "; ".join(notes)
+        dist.barrier(group=_CTRL if _CTRL is not None else ctrl)
+
+    def one_step(k=None, events=None):
+        if halo == "native":
+            if events:
+                events[0].record()
+            sh.step_native(src, dst)
+            if events:
+                events[1].record()
         else:
-            transport = "gloo (host-staged REHEARSAL)"
-            sh.step(src, dst)
-            torch.cuda.synchronize(dev)
-            dist.barrier()
+            sh.step(src, dst, events=events)
 
     for _ in range(args.warmup):
-        sh.step(src, dst)
+        one_step()
     torch.cuda.synchronize(dev)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    dt = timed_region(world, dev, args.steps, lambda k: sh.step(src, dst, events=ev[k]))
+    dt = timed_region(world, dev, args.steps, lambda k: one_step(k, ev[k]))
 
     out_values = nxo * nyo * nc
     mpix = out_values * args.steps / dt / 1e6
@@ -307,6 +338,8 @@ def bench_reproject(args, rank, world, dev):
     k_avg_ms = sum(kms) / len(kms)
     if world == 1:
         launch_out_rows, launch_src_rows = nyo, ny
+    elif halo == "native":                       # the events bracket the whole sharded step of this rank
+        launch_out_rows, launch_src_rows = sh.dst_window[1], sh.src_window[1]
     elif sh.interior[1] > sh.interior[0]:
         launch_out_rows = sh.interior[1] - sh.interior[0]
         launch_src_rows = sh.own[rank][1] - sh.own[rank][0]
@@ -325,13 +358,14 @@ def bench_reproject(args, rank, world, dev):
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": desc, "shape_in": list(shape_in), "shape_out": list(shape_out) + [nc],
-                   "parallelism": "dec-strip x%d, %d-row halo via %s send/recv" % (
+                   "parallelism": "dec-strip x%d, %d-row halo via %s" % (
                        world, max([hi - lo for _, lo, hi in sh.recvs + sh.sends], default=0),
                        transport),
                    "halo_bytes_per_message": max([(hi - lo) * nx * nc * 8 for _, lo, hi in sh.recvs + sh.sends], default=0),
                    "bytes_per_output_value": round(8.0 * (nx * ny + nxo * nyo) / (nxo * nyo), 3),
                    "buffer_placement": placement},
-        "roofline": {"bound": "hbm", "kernel": "k_reproject_dma",
+        "roofline": {"bound": "hbm",
+                     "kernel": "k_reproject_dma" + (" (whole sharded step: exchange wait + interior + boundary launches)" if halo == "native" and world > 1 else ""),
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic,

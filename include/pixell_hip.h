@@ -160,6 +160,31 @@ int pxl_reproject_plan_rows_covered(const pxl_reproject_plan* plan, int64_t have
 int pxl_reproject_plan_set_variant(pxl_reproject_plan* plan, int variant);
 int pxl_reproject_plan_destroy(pxl_reproject_plan* plan);
 
+/* ---- One step of the dec-strip sharded operator on this rank: exchange halo rows with the
+ *      neighbouring ranks over RCCL send/recv, reproject the output rows that need only owned rows while the
+ *      halo travels, then the rest.  The plan describes this rank's windows: src is its resident buffer
+ *      ([nc,] src_nrows, nx) holding the rows it owns -- [own_row0, own_row0 + own_nrows), absolute -- with room
+ *      for the halo rows around them; sends/recvs list absolute source rows (one RCCL message per component plane,
+ *      straight from/into src: nothing is staged).  rccl_comm is the caller's ncclComm_t (one rank per GPU); the
+ *      RCCL functions are looked up in the RCCL instance already loaded in the process (PXL_RCCL_LIB overrides),
+ *      so this library has no link-time RCCL dependency.  The exchange runs on a stream owned by the plan,
+ *      ordered after everything queued on `stream` before the call; the function does not synchronise.
+ *      With no transfers (one rank) it is build_tables + execute.  No reference counterpart.                    */
+typedef struct pxl_halo_xfer {
+    int32_t peer;        /* rank in rccl_comm */
+    int32_t reserved;
+    int64_t row0;        /* first source row of the transfer, 0-based, absolute */
+    int64_t nrows;
+} pxl_halo_xfer;
+int pxl_reproject_sharded_step_f64(pxl_reproject_plan* plan, double* src, double* dst,
+                                   int64_t own_row0, int64_t own_nrows,
+                                   const pxl_halo_xfer* sends, int nsends, const pxl_halo_xfer* recvs, int nrecvs,
+                                   void* rccl_comm, void* stream);
+int pxl_reproject_sharded_step_f32(pxl_reproject_plan* plan, float* src, float* dst,
+                                   int64_t own_row0, int64_t own_nrows,
+                                   const pxl_halo_xfer* sends, int nsends, const pxl_halo_xfer* recvs, int nrecvs,
+                                   void* rccl_comm, void* stream);
+
 /* one-shot convenience (creates a plan, executes, synchronises `stream`, destroys) */
 int pxl_reproject_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], const double* src,
                                    const pxl_car_wcs* wcs_out, const int64_t shape_out[2], double* dst,

@@ -58,6 +58,8 @@ SIGNATURES = {
     "pxl_reproject_plan_rows_covered": (C.c_int, [_P, _I64, _I64, C.POINTER(_I64), C.POINTER(_I64)]),
     "pxl_reproject_plan_set_variant": (C.c_int, [_P, C.c_int]),
     "pxl_reproject_plan_destroy": (C.c_int, [_P]),
+    "pxl_reproject_sharded_step_f64": (C.c_int, [_P, _P, _P, _I64, _I64, _P, C.c_int, _P, C.c_int, _P, _P]),
+    "pxl_reproject_sharded_step_f32": (C.c_int, [_P, _P, _P, _I64, _I64, _P, C.c_int, _P, C.c_int, _P, _P]),
     "pxl_reproject_car_bilinear_f64": (C.c_int, [_WP, _SHP, _P, _WP, _SHP, _P, _P]),
     "pxl_reproject_generic_bilinear_f64": (C.c_int, [_WP, C.c_int, _SHP, _P, _WP, C.c_int, _SHP, _P, _P]),
     "pxl_sample_car_bilinear_f64": (C.c_int, [_WP, _SHP, _P, _I64, _I64, _I64, _P, _P, _P]),
@@ -103,6 +105,19 @@ def last_error():
 def check(rc):
     if rc != 0:
         raise PixellHipError(rc, last_error())
+
+
+class HaloXfer(C.Structure):
+    """struct pxl_halo_xfer"""
+    _fields_ = [("peer", C.c_int32), ("reserved", C.c_int32), ("row0", C.c_int64), ("nrows", C.c_int64)]
+
+
+def xfer_arr(items):
+    """(peer, row_lo, row_hi) triples -> a pxl_halo_xfer array (absolute source rows)."""
+    arr = (HaloXfer * max(1, len(items)))()
+    for k, (peer, lo, hi) in enumerate(items):
+        arr[k].peer, arr[k].reserved, arr[k].row0, arr[k].nrows = int(peer), 0, int(lo), int(hi - lo)
+    return arr
 
 
 def shape_arr(vals):

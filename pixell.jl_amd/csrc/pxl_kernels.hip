@@ -83,6 +83,7 @@ static int env_int(const char* name, int dflt) {
 #include "pxl_reproject_dma.h"
 #include "pxl_sample.h"
 #include "pxl_misc.h"
+#include "pxl_rccl.h"
 
 // ================================================================================================
 // C ABI
@@ -116,6 +117,10 @@ struct pxl_reproject_plan {
     bool staged_ok;
     bool vec_load;
     bool tables_built;
+    // sharded step: the halo exchange runs on a stream of its own, fenced by two events
+    hipStream_t comm_stream;
+    hipEvent_t ev_ready, ev_halo;
+    int64_t cov_have_lo, cov_have_hi, cov_lo, cov_hi;     // cached pxl_reproject_plan_rows_covered answer
 };
 
 // Scratch of one unwind! call, from the stream-ordered allocator (hipMallocAsync / hipFreeAsync): no host
@@ -503,8 +508,9 @@ int pxl_reproject_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[
     if (dst_row0 < 0 || dst_nrows < 0 || dst_row0 + dst_nrows > shape_out[1])
         return fail(PXL_EINVAL, "plan_create: destination window outside the map");
 
-    pxl_reproject_plan* pl = new (std::nothrow) pxl_reproject_plan();
+    pxl_reproject_plan* pl = new (std::nothrow) pxl_reproject_plan();     // value-initialised: all members zero
     if (!pl) return fail(PXL_ENOMEM, "plan_create: host allocation failed");
+    pl->cov_lo = 0; pl->cov_hi = -1;                                        // no cached interior yet
     pl->win = *wcs_in; pl->wout = *wcs_out;
     pl->nx = shape_in[0]; pl->ny = shape_in[1]; pl->nc = shape_in[2];
     pl->src_row0 = src_row0; pl->src_nrows = src_nrows;
@@ -610,6 +616,12 @@ int pxl_reproject_plan_set_variant(pxl_reproject_plan* pl, int variant) {
 
 int pxl_reproject_plan_destroy(pxl_reproject_plan* pl) {
     if (!pl) return PXL_OK;
+    if (pl->comm_stream) {
+        (void)hipStreamSynchronize(pl->comm_stream);
+        (void)hipEventDestroy(pl->ev_ready);
+        (void)hipEventDestroy(pl->ev_halo);
+        (void)hipStreamDestroy(pl->comm_stream);
+    }
     if (pl->table_mem) (void)hipFree(pl->table_mem);
     delete[] pl->h_yj0;
     delete pl;
@@ -753,6 +765,100 @@ int pxl_reproject_plan_rows_covered(const pxl_reproject_plan* pl, int64_t have_l
     }
     *lo = best_lo; *hi = best_hi;
     return PXL_OK;
+}
+
+// ---- sharded step: halo rows over RCCL send/recv, interior rows while they travel, boundary rows after
+static int sharded_step_impl(pxl_reproject_plan* pl, void* src, void* dst, int64_t own_row0, int64_t own_nrows,
+                             const pxl_halo_xfer* sends, int nsends, const pxl_halo_xfer* recvs, int nrecvs,
+                             void* comm, void* stream, int dtype) {
+    if (!pl || !src || !dst) return fail(PXL_EINVAL, "sharded_step: null plan or buffer");
+    if (nsends < 0 || nrecvs < 0 || (nsends > 0 && !sends) || (nrecvs > 0 && !recvs)) return fail(PXL_EINVAL, "sharded_step: bad transfer lists");
+    const int64_t lo = pl->src_row0, hi = pl->src_row0 + pl->src_nrows;
+    if (own_row0 < lo || own_nrows < 0 || own_row0 + own_nrows > hi) return fail(PXL_EINVAL, "sharded_step: owned rows outside the plan's source window");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = PXL_OK;
+    const bool exchange = nsends + nrecvs > 0;
+    if (exchange) {
+        if (!comm) return fail(PXL_EINVAL, "sharded_step: transfers listed but no RCCL communicator");
+        const RcclApi& nc = rccl_api();
+        if (!nc.ok) return fail(PXL_ENODEV, "sharded_step: RCCL entry points not available: %s", nc.where);
+        int nranks = 0, me = -1;
+        if (nc.CommCount((ncclComm_t)comm, &nranks) != ncclSuccess || nc.CommUserRank((ncclComm_t)comm, &me) != ncclSuccess)
+            return fail(PXL_EINVAL, "sharded_step: not a usable RCCL communicator");
+        for (int pass = 0; pass < 2; ++pass) {
+            const pxl_halo_xfer* x = pass == 0 ? sends : recvs;
+            for (int i = 0; i < (pass == 0 ? nsends : nrecvs); ++i) {
+                if (x[i].peer < 0 || x[i].peer >= nranks) return fail(PXL_EINVAL, "sharded_step: peer %d outside the communicator (%d ranks)", x[i].peer, nranks);
+                if (x[i].nrows < 1 || x[i].row0 < lo || x[i].row0 + x[i].nrows > hi) return fail(PXL_EINVAL, "sharded_step: transfer rows outside the plan's source window");
+                if (pass == 0 && (x[i].row0 < own_row0 || x[i].row0 + x[i].nrows > own_row0 + own_nrows))
+                    return fail(PXL_EINVAL, "sharded_step: a rank can only send rows it owns");
+            }
+        }
+        if (!pl->comm_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&pl->comm_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&pl->ev_ready, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&pl->ev_halo, hipEventDisableTiming));
+        }
+        // the exchange may start once everything queued on the caller's stream so far (the producers of src, the
+        // previous step's readers of the halo rows) is done
+        HIP_TRY(hipEventRecord(pl->ev_ready, st));
+        HIP_TRY(hipStreamWaitEvent(pl->comm_stream, pl->ev_ready, 0));
+        const size_t esz = (size_t)dtype;
+        const ncclDataType_t dt = dtype == 4 ? ncclFloat32 : ncclFloat64;
+        ncclResult_t r = nc.GroupStart();
+        // one message per component plane and transfer: rows of one plane are contiguous in the resident buffer,
+        // so nothing is staged
+        for (int i = 0; i < nsends && r == ncclSuccess; ++i)
+            for (int64_t c = 0; c < pl->nc && r == ncclSuccess; ++c)
+                r = nc.Send((const char*)src + ((c * pl->src_nrows + (sends[i].row0 - lo)) * pl->nx) * esz,
+                            (size_t)(sends[i].nrows * pl->nx), dt, sends[i].peer, (ncclComm_t)comm, pl->comm_stream);
+        for (int i = 0; i < nrecvs && r == ncclSuccess; ++i)
+            for (int64_t c = 0; c < pl->nc && r == ncclSuccess; ++c)
+                r = nc.Recv((char*)src + ((c * pl->src_nrows + (recvs[i].row0 - lo)) * pl->nx) * esz,
+                            (size_t)(recvs[i].nrows * pl->nx), dt, recvs[i].peer, (ncclComm_t)comm, pl->comm_stream);
+        const ncclResult_t rend = nc.GroupEnd();
+        if (r == ncclSuccess) r = rend;
+        if (r != ncclSuccess) return fail(PXL_EHIP, "sharded_step: RCCL send/recv failed: %s", nc.GetErrorString(r));
+        HIP_TRY(hipEventRecord(pl->ev_halo, pl->comm_stream));
+    }
+    rc = pxl_reproject_build_tables(pl, stream);
+    if (rc) return rc;
+    // rows computable from the rows this rank owns run while the halo is in flight
+    int64_t i_lo = 0, i_hi = pl->dst_nrows;
+    if (exchange) {
+        if (pl->cov_have_lo != own_row0 || pl->cov_have_hi != own_row0 + own_nrows || pl->cov_hi < pl->cov_lo) {
+            rc = pxl_reproject_plan_rows_covered(pl, own_row0, own_row0 + own_nrows, &pl->cov_lo, &pl->cov_hi);
+            if (rc) return rc;
+            pl->cov_have_lo = own_row0; pl->cov_have_hi = own_row0 + own_nrows;
+        }
+        i_lo = pl->cov_lo; i_hi = pl->cov_hi;
+    }
+    if (i_hi > i_lo) {
+        rc = reproject_rows_impl(pl, src, dst, i_lo, i_hi - i_lo, stream, dtype);
+        if (rc) return rc;
+    }
+    if (exchange) {
+        HIP_TRY(hipStreamWaitEvent(st, pl->ev_halo, 0));
+        if (i_hi > i_lo) {
+            if (i_lo > 0) { rc = reproject_rows_impl(pl, src, dst, 0, i_lo, stream, dtype); if (rc) return rc; }
+            if (i_hi < pl->dst_nrows) rc = reproject_rows_impl(pl, src, dst, i_hi, pl->dst_nrows - i_hi, stream, dtype);
+        } else {
+            rc = reproject_rows_impl(pl, src, dst, 0, pl->dst_nrows, stream, dtype);
+        }
+    }
+    return rc;
+}
+
+int pxl_reproject_sharded_step_f64(pxl_reproject_plan* plan, double* src, double* dst, int64_t own_row0, int64_t own_nrows,
+                                   const pxl_halo_xfer* sends, int nsends, const pxl_halo_xfer* recvs, int nrecvs,
+                                   void* rccl_comm, void* stream) {
+    return sharded_step_impl(plan, src, dst, own_row0, own_nrows, sends, nsends, recvs, nrecvs, rccl_comm, stream, 8);
+}
+
+int pxl_reproject_sharded_step_f32(pxl_reproject_plan* plan, float* src, float* dst, int64_t own_row0, int64_t own_nrows,
+                                   const pxl_halo_xfer* sends, int nsends, const pxl_halo_xfer* recvs, int nrecvs,
+                                   void* rccl_comm, void* stream) {
+    return sharded_step_impl(plan, src, dst, own_row0, own_nrows, sends, nsends, recvs, nrecvs, rccl_comm, stream, 4);
 }
 
 int pxl_reproject_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], const double* src,

@@ -184,12 +184,38 @@ class DecStripReprojector(DecStripLayout):
         self.plan = ReprojectPlan(self.shape_in, wcs_in, self.shape_out, wcs_out, src_rows=self.src_window,
                                   dst_rows=self.dst_window, device=self.device)
         self._staging = None
+        self._xfers = None
 
     def alloc_src(self):
         return torch.zeros(self.src_tensor_shape(), dtype=torch.float64, device=self.device)
 
     def alloc_dst(self):
         return torch.empty(self.dst_tensor_shape(), dtype=torch.float64, device=self.device)
+
+    def rccl_comm_ptr(self):
+        """The ncclComm_t of this job's RCCL process group, for the native step (ProcessGroupNCCL._comm_ptr)."""
+        pg = self.group if self.group is not None else dist.distributed_c10d._get_default_group()
+        return int(pg._get_backend(self.device)._comm_ptr())
+
+    def step_native(self, src: torch.Tensor, dst: torch.Tensor, comm_ptr=None):
+        """The same pass through the library's own sharded entry (pxl_reproject_sharded_step_*): RCCL send/recv
+        issued by the library straight from/into the resident buffer (no staging copies, no Python in the loop),
+        interior rows while the halo travels.  comm_ptr: an ncclComm_t (default: this job's RCCL group)."""
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        if self._xfers is None:
+            self._xfers = (_lib.xfer_arr(self.sends), _lib.xfer_arr(self.recvs))
+        if comm_ptr is None and (self.sends or self.recvs):
+            comm_ptr = self.rccl_comm_ptr()
+        fn = lib.pxl_reproject_sharded_step_f32 if src.dtype == torch.float32 else lib.pxl_reproject_sharded_step_f64
+        own_lo, own_hi = self.own[self.rank]
+        with torch.cuda.device(self.device):
+            s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(fn(self.plan._h, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), own_lo, own_hi - own_lo,
+                          C.cast(self._xfers[0], C.c_void_p), len(self.sends), C.cast(self._xfers[1], C.c_void_p), len(self.recvs),
+                          C.c_void_p(comm_ptr or 0), s))
+        return dst
 
     def step(self, src: torch.Tensor, dst: torch.Tensor, events=None):
         """One pass: exchange halos, reproject this rank's output strip.  Asynchronous on the current stream.
