@@ -176,5 +176,21 @@ function Pixell.unwind!(angles::HIPArray{Float64,N}; dims=N, period=2π, ref_ang
     return angles
 end
 
-export HIPArray, posmap_device, reproject, reproject!, ReprojectPlan, sample_bilinear
+# ---- one step of the dec-strip sharded operator on this rank (one process per GPU): the library exchanges the halo
+#      rows over the host's RCCL communicator (`comm::Ptr{Cvoid}` = ncclComm_t) and orders interior / boundary rows
+struct HaloXfer                    # == struct pxl_halo_xfer
+    peer::Int32
+    reserved::Int32
+    row0::Int64                    # 0-based absolute source row
+    nrows::Int64
+end
+function sharded_step!(dst::HIPArray{Float64}, plan::ReprojectPlan, src::HIPArray{Float64}, own_rows::Tuple{Int,Int},
+                       sends::Vector{HaloXfer}, recvs::Vector{HaloXfer}, comm::Ptr{Cvoid})
+    GC.@preserve src dst sends recvs check(ccall((:pxl_reproject_sharded_step_f64, libpixell_hip), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Int64, Ptr{HaloXfer}, Cint, Ptr{HaloXfer}, Cint, Ptr{Cvoid}, Ptr{Cvoid}),
+        plan.handle, src.ptr, dst.ptr, own_rows[1], own_rows[2], sends, length(sends), recvs, length(recvs), comm, NULLSTREAM))
+    return dst
+end
+
+export HIPArray, posmap_device, reproject, reproject!, ReprojectPlan, sample_bilinear, HaloXfer, sharded_step!
 end # module
