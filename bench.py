@@ -179,7 +179,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=os.environ.get("PXL_BENCH_WORKLOAD", "cfg4"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--placements", type=int, default=int(os.environ.get("PXL_BENCH_PLACEMENTS", "4")),
+    ap.add_argument("--placements", type=int, default=int(os.environ.get("PXL_BENCH_PLACEMENTS", "8")),
                     help="buffer placements tried at setup (1 = take the first allocation)")
     ap.add_argument("--check", action="store_true", help="verify a sample of the output against the oracle")
     ap.add_argument("--halo", default="auto", choices=["auto", "native", "torch", "gloo"],

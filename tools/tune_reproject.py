@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--workload", default="cfg4")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--placements", type=int, default=1, help="re-allocate the maps this many times (physical placement moves the kernel by up to 10 %%) and print every variant per placement")
     ap.add_argument("--strip", default=None, help="R/W: time the declination strip of rank R of W (interior rows only)")
     ap.add_argument("variants", nargs="+")
     args = ap.parse_args()
@@ -61,26 +62,41 @@ def main():
                 k, val = kv.split("=")
                 os.environ[KEYS[k]] = val
         plans.append(pj.ReprojectPlan(shape_in, wcs_in, shape_out, wcs_out, src_rows=src_rows, dst_rows=dst_rows, device=dev))
-    for pl in plans:
-        pl.build_tables()
-        pl.execute_rows(src, dst, r0, nr)       # warm-up
-    torch.cuda.synchronize()
-    times = [[] for _ in plans]
-    for _ in range(args.rounds):
-        for i, pl in enumerate(plans):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            pl.execute_rows(src, dst, r0, nr)
-            e1.record()
-            torch.cuda.synchronize()
-            times[i].append(e0.elapsed_time(e1))
+    import random
     alg = (4.0 if args.dtype == "f32" else 8.0) * nc * (nx * ny_s + nxo * nr)
     print("workload:", desc)
-    for v, t in zip(args.variants, times):
-        t = sorted(t)
-        med, mn = t[len(t) // 2], t[0]
-        print("%-40s median %8.4f ms  min %8.4f ms  -> %7.1f GB/s (%.1f%% of 8 TB/s)" % (
-            v, med, mn, alg / med / 1e6, alg / med / 1e6 / 80.0))
+    keep = []
+    for place in range(args.placements):
+        if place > 0:                                # move the maps: free, perturb the heap, allocate again
+            tdt = src.dtype
+            del src, dst
+            keep.append(torch.empty(int(random.uniform(0.3, 3.0) * 2**30), dtype=torch.uint8, device=dev))
+            keep = keep[-2:]
+            torch.cuda.empty_cache()
+            src = torch.randn((nc, ny_s, nx), dtype=tdt, device=dev) if tdt == torch.float32 else torch.empty((nc, ny_s, nx), dtype=tdt, device=dev)
+            if tdt == torch.float64:
+                pj.fill_random_(src, 1234)
+            dst = torch.empty((nc, nyo_s, nxo), dtype=tdt, device=dev)
+        for pl in plans:
+            pl.build_tables()
+            pl.execute_rows(src, dst, r0, nr)       # warm-up
+        torch.cuda.synchronize()
+        times = [[] for _ in plans]
+        for _ in range(args.rounds):
+            for i, pl in enumerate(plans):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                pl.execute_rows(src, dst, r0, nr)
+                e1.record()
+                torch.cuda.synchronize()
+                times[i].append(e0.elapsed_time(e1))
+        if args.placements > 1:
+            print("-- placement %d" % place)
+        for v, t in zip(args.variants, times):
+            t = sorted(t)
+            med, mn = t[len(t) // 2], t[0]
+            print("%-40s median %8.4f ms  min %8.4f ms  -> %7.1f GB/s (%.1f%% of 8 TB/s)" % (
+                v, med, mn, alg / med / 1e6, alg / med / 1e6 / 80.0))
 
 
 if __name__ == "__main__":
