@@ -112,3 +112,15 @@ def test_streamed_io_many_chunks(pj, tmp_path, monkeypatch):
     open(cut, "wb").write(open(path, "rb").read()[:off + 1000])
     with pytest.raises(ValueError):
         pj.read_map(cut, device="cuda:0")
+
+
+def test_header_units(pj):
+    """getunit of the header's CUNIT (arbitrary_wcs.jl:16-34; test_enmap.jl:155-162): deg, rad, arcmin, arcsec, mas,
+    unknown -> degrees; mixed units are refused (the reference asserts)."""
+    h, _ = pj.read_header(FIXTURE)
+    for cunit, unit in (("deg", np.pi / 180), ("rad", 1.0), ("arcmin", np.pi / 180 / 60), ("arcsec", np.pi / 180 / 60 / 60),
+                        ("mas", np.pi / 180 / 60 / 60 / 1000), ("furlong", np.pi / 180)):
+        h2 = dict(h, CUNIT1=cunit, CUNIT2=cunit)
+        assert abs(pj.wcs_from_header(h2).unit - unit) <= 1e-18 * max(1.0, unit)
+    with pytest.raises(AssertionError):
+        pj.wcs_from_header(dict(h, CUNIT1="deg", CUNIT2="rad"))
