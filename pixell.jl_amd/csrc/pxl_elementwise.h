@@ -6,7 +6,9 @@
 // ------------------------------------------------------------------------------------------------
 // Each lane handles UNR points per trip, all loads issued before the arithmetic so several 16-B requests
 // per lane are in flight (a single dependent load/store per trip left the stream at 57 % of HBM peak).
+#ifndef PXL_UNR
 #define PXL_UNR 4
+#endif
 __global__ __launch_bounds__(256) void k_pix2sky_pairs(CarAffine c, int64_t n, const double2* pix,
                                                        double2* sky, int mode, const int32_t* gate) {
     if (gate && *gate == 0) return;      // fallback launches of the unwind path: run only when the fused form failed
