@@ -4,11 +4,10 @@
 // ------------------------------------------------------------------------------------------------
 // elementwise evaluators (A9-A13): one (c1, c2) pair = 16 B in, 16 B out per lane
 // ------------------------------------------------------------------------------------------------
-// Each lane handles UNR points per trip, all loads issued before the arithmetic so several 16-B requests
-// per lane are in flight (a single dependent load/store per trip left the stream at 57 % of HBM peak).
-#ifndef PXL_UNR
-#define PXL_UNR 4
-#endif
+// Each lane handles UNR points per trip, all loads issued before the arithmetic.  With one contiguous chunk per block
+// the affine-only forms are fastest at UNR = 1 (2.10 vs 2.27 ms per 4e8 points, same-box A/B: 76 % of the HBM peak,
+// the mixed read/write ceiling of the part); the forms that rewind (two exact fmod per point) prefer 2.
+template <int PXL_UNR>
 __global__ __launch_bounds__(256) void k_pix2sky_pairs(CarAffine c, int64_t n, const double2* pix,
                                                        double2* sky, int mode, const int32_t* gate) {
     if (gate && *gate == 0) return;      // fallback launches of the unwind path: run only when the fused form failed
@@ -47,6 +46,7 @@ __global__ __launch_bounds__(256) void k_pix2sky_soa(CarAffine c, int64_t n, con
     }
 }
 
+template <int PXL_UNR>
 __global__ __launch_bounds__(256) void k_sky2pix_pairs(Sky2Pix s, int64_t n, const double2* sky,
                                                        double2* pix) {
     const int64_t chunk = (int64_t)blockDim.x * PXL_UNR;

@@ -298,9 +298,14 @@ int pxl_pix2sky_car_f64(const pxl_car_wcs* wcs, int64_t n, const double* pix, do
     hipStream_t st = (hipStream_t)stream;
     CarAffine c = car_affine(*wcs);
     const int mode = wrap_mode == PXL_WRAP_REWIND ? 1 : (wrap_mode == PXL_WRAP_UNWIND ? 2 : 0);
-    const dim3 pgrid(stream_grid((n + PXL_UNR - 1) / PXL_UNR, 256));
+    if (wrap_mode == PXL_WRAP_NONE) {          // affine only: one point per lane per trip
+        hipLaunchKernelGGL((k_pix2sky_pairs<1>), dim3(stream_grid(n, 256)), dim3(256), 0, st, c, n, (const double2*)pix,
+                           (double2*)sky, mode, (const int32_t*)nullptr);
+        return check_launch("k_pix2sky_pairs");
+    }
+    const dim3 pgrid(stream_grid((n + 1) / 2, 256));
     if (wrap_mode != PXL_WRAP_UNWIND) {
-        hipLaunchKernelGGL(k_pix2sky_pairs, pgrid, dim3(256), 0, st, c, n, (const double2*)pix, (double2*)sky, mode,
+        hipLaunchKernelGGL((k_pix2sky_pairs<2>), pgrid, dim3(256), 0, st, c, n, (const double2*)pix, (double2*)sky, mode,
                            (const int32_t*)nullptr);
         return check_launch("k_pix2sky_pairs");
     }
@@ -323,7 +328,7 @@ int pxl_pix2sky_car_f64(const pxl_car_wcs* wcs, int64_t n, const double* pix, do
             hipLaunchKernelGGL((k_unwind_block<UwSrcPix2>), dim3(1), dim3(1024), 0, st, src, (double2*)sky, n, failed);
             rc = check_launch("k_unwind_block");
         } else {
-            hipLaunchKernelGGL(k_pix2sky_pairs, dim3(std::min(pgrid.x, 2048u)), dim3(256), 0, st, c, n, (const double2*)pix, (double2*)sky, 2, failed);
+            hipLaunchKernelGGL((k_pix2sky_pairs<2>), dim3(std::min(pgrid.x, 2048u)), dim3(256), 0, st, c, n, (const double2*)pix, (double2*)sky, 2, failed);
             rc = check_launch("k_pix2sky_pairs");
             if (rc == PXL_OK) rc = unwind_multipass(n, 2, sky, PXL_TWOPI_D, 0.0, w, failed, st);
         }
@@ -400,8 +405,12 @@ int pxl_sky2pix_car_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64_t 
     if ((((uintptr_t)pix | (uintptr_t)sky) & 15) != 0) return fail(PXL_EINVAL, "sky2pix: 2xN buffers must be 16-byte aligned");
     if (n == 0) return PXL_OK;
     Sky2Pix s = sky2pix_setup(*wcs, shape[0], shape[1], safe ? 1 : 0, form);
-    hipLaunchKernelGGL(k_sky2pix_pairs, dim3(stream_grid((n + PXL_UNR - 1) / PXL_UNR, 256)), dim3(256), 0,
-                       (hipStream_t)stream, s, n, (const double2*)sky, (double2*)pix);
+    if (safe)
+        hipLaunchKernelGGL((k_sky2pix_pairs<2>), dim3(stream_grid((n + 1) / 2, 256)), dim3(256), 0,
+                           (hipStream_t)stream, s, n, (const double2*)sky, (double2*)pix);
+    else
+        hipLaunchKernelGGL((k_sky2pix_pairs<1>), dim3(stream_grid(n, 256)), dim3(256), 0,
+                           (hipStream_t)stream, s, n, (const double2*)sky, (double2*)pix);
     return check_launch("k_sky2pix_pairs");
 }
 

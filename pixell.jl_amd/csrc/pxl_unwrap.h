@@ -173,7 +173,9 @@ __global__ __launch_bounds__(256) void k_unwrap_apply(int64_t n, int nrow, doubl
 // In-place calls verify first (no store) and store in a second, device-gated launch, so the input survives for
 // the fallback.
 // ------------------------------------------------------------------------------------------------
+#ifndef PXL_UW_G
 #define PXL_UW_G 4          // 16-byte loads in flight per lane
+#endif
 
 struct UwSrcPix2 {          // m = rewind(pix2sky affine) - ref, ref = 0   (pix2sky!(...; safe=true), car_proj.jl:104-112)
     static constexpr int NROW = 2;
