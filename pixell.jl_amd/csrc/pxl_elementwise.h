@@ -34,15 +34,26 @@ __global__ __launch_bounds__(256) void k_pix2sky_pairs(CarAffine c, int64_t n, c
     }
 }
 
+// SoA forms: two adjacent points per lane so that every access is 16 B per lane (1 KiB per wave instruction); `vec`
+// = all four arrays 16-byte aligned (otherwise, and for an odd last point, scalar accesses).
 __global__ __launch_bounds__(256) void k_pix2sky_soa(CarAffine c, int64_t n, const double* __restrict__ ip,
                                                      const double* __restrict__ jp, double* __restrict__ ra,
-                                                     double* __restrict__ dec, int safe) {
+                                                     double* __restrict__ dec, int safe, int vec) {
+    const int64_t npair = (n + 1) / 2;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-        double a = p2s_ra(c, ip[k]);
-        double d = p2s_dec(c, jp[k]);
-        if (safe) { a = rewind(a, PXL_TWOPI_D, 0.0); d = rewind(d, PXL_TWOPI_D, 0.0); }
-        ra[k] = a; dec[k] = d;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < npair; t += stride) {
+        const int64_t k = 2 * t;
+        const bool two = k + 1 < n;
+        double2 pi, pj;
+        if (vec && two) { pi = *reinterpret_cast<const double2*>(ip + k); pj = *reinterpret_cast<const double2*>(jp + k); }
+        else { pi.x = ip[k]; pj.x = jp[k]; pi.y = two ? ip[k + 1] : 0.0; pj.y = two ? jp[k + 1] : 0.0; }
+        double a0 = p2s_ra(c, pi.x), d0 = p2s_dec(c, pj.x), a1 = p2s_ra(c, pi.y), d1 = p2s_dec(c, pj.y);
+        if (safe) {
+            a0 = rewind(a0, PXL_TWOPI_D, 0.0); d0 = rewind(d0, PXL_TWOPI_D, 0.0);
+            a1 = rewind(a1, PXL_TWOPI_D, 0.0); d1 = rewind(d1, PXL_TWOPI_D, 0.0);
+        }
+        if (vec && two) { *reinterpret_cast<double2*>(ra + k) = make_double2(a0, a1); *reinterpret_cast<double2*>(dec + k) = make_double2(d0, d1); }
+        else { ra[k] = a0; dec[k] = d0; if (two) { ra[k + 1] = a1; dec[k + 1] = d1; } }
     }
 }
 
@@ -67,10 +78,17 @@ __global__ __launch_bounds__(256) void k_sky2pix_pairs(Sky2Pix s, int64_t n, con
 
 __global__ __launch_bounds__(256) void k_sky2pix_soa(Sky2Pix s, int64_t n, const double* __restrict__ ra,
                                                      const double* __restrict__ dec, double* __restrict__ ip,
-                                                     double* __restrict__ jp) {
+                                                     double* __restrict__ jp, int vec) {
+    const int64_t npair = (n + 1) / 2;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-        ip[k] = s2p_x(s, ra[k]);
-        jp[k] = s2p_y(s, dec[k]);
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < npair; t += stride) {
+        const int64_t k = 2 * t;
+        const bool two = k + 1 < n;
+        double2 a, d;
+        if (vec && two) { a = *reinterpret_cast<const double2*>(ra + k); d = *reinterpret_cast<const double2*>(dec + k); }
+        else { a.x = ra[k]; d.x = dec[k]; a.y = two ? ra[k + 1] : 0.0; d.y = two ? dec[k + 1] : 0.0; }
+        const double x0 = s2p_x(s, a.x), y0 = s2p_y(s, d.x), x1 = s2p_x(s, a.y), y1 = s2p_y(s, d.y);
+        if (vec && two) { *reinterpret_cast<double2*>(ip + k) = make_double2(x0, x1); *reinterpret_cast<double2*>(jp + k) = make_double2(y0, y1); }
+        else { ip[k] = x0; jp[k] = y0; if (two) { ip[k + 1] = x1; jp[k + 1] = y1; } }
     }
 }

@@ -392,8 +392,9 @@ int pxl_pix2sky_car_soa_f64(const pxl_car_wcs* wcs, int64_t n, const double* ipi
     if (!wcs_ok(wcs)) return fail(PXL_EINVAL, "pix2sky_soa: invalid WCS");
     if (n < 0 || (n > 0 && (!ipix || !jpix || !ra || !dec))) return fail(PXL_EINVAL, "pix2sky_soa: null buffer or negative n");
     if (n == 0) return PXL_OK;
-    hipLaunchKernelGGL(k_pix2sky_soa, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       car_affine(*wcs), n, ipix, jpix, ra, dec, safe ? 1 : 0);
+    const int vec = ((((uintptr_t)ipix | (uintptr_t)jpix | (uintptr_t)ra | (uintptr_t)dec) & 15) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(k_pix2sky_soa, dim3(stream_grid((n + 1) / 2, 256)), dim3(256), 0, (hipStream_t)stream,
+                       car_affine(*wcs), n, ipix, jpix, ra, dec, safe ? 1 : 0, vec);
     return check_launch("k_pix2sky_soa");
 }
 
@@ -421,8 +422,9 @@ int pxl_sky2pix_car_soa_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int6
     if (form < 0 || form > 2) return fail(PXL_EINVAL, "sky2pix_soa: bad form %d", form);
     if (n == 0) return PXL_OK;
     Sky2Pix s = sky2pix_setup(*wcs, shape[0], shape[1], safe ? 1 : 0, form);
-    hipLaunchKernelGGL(k_sky2pix_soa, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, s, n, ra,
-                       dec, ipix, jpix);
+    const int vec = ((((uintptr_t)ipix | (uintptr_t)jpix | (uintptr_t)ra | (uintptr_t)dec) & 15) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(k_sky2pix_soa, dim3(stream_grid((n + 1) / 2, 256)), dim3(256), 0, (hipStream_t)stream, s, n, ra,
+                       dec, ipix, jpix, vec);
     return check_launch("k_sky2pix_soa");
 }
 

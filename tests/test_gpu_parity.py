@@ -849,3 +849,23 @@ def test_reproject_every_tile_shape(pj, O, dev, f32, monkeypatch):
             else:
                 assert bits_equal(got, O.reproject(wcs_in, (nx_in, ny_in, 2), src, wcs_out, shape_out)), (pairs, sx)
             plan.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 1000, 100001])
+def test_soa_forms_unaligned_and_odd(pj, O, dev, n):
+    """The SoA kernels take two points per lane with 16-byte accesses when all four arrays allow it; vectors that
+    start 8 bytes off (views into a larger tensor) and odd lengths take the scalar accesses -- same bits either way."""
+    shape, wcs = pj.fullsky_geometry(1 * DEG)
+    rng = np.random.default_rng(n)
+    a, b = rng.uniform(-400, 400, n + 1), rng.uniform(-200, 200, n + 1)
+    for off in (0, 1):
+        da, db = to_dev(a, dev)[off:off + n], to_dev(b, dev)[off:off + n]
+        assert da.is_contiguous() and (da.data_ptr() % 16 == 0) == (off == 0)
+        for safe in (True, False):
+            ra, dec = pj.pix2sky((shape, wcs), da, db, safe=safe)
+            era, edec = O.pix2sky_soa(wcs, a[off:off + n], b[off:off + n], safe=safe)
+            assert bits_equal(ra.cpu().numpy(), era) and bits_equal(dec.cpu().numpy(), edec), (n, off, safe)
+            sa, sb = to_dev(a * 0.01, dev)[off:off + n], to_dev(b * 0.01, dev)[off:off + n]
+            x, y = pj.sky2pix((shape, wcs), sa, sb, safe=safe)
+            ex, ey = O.sky2pix_soa(wcs, shape, a[off:off + n] * 0.01, b[off:off + n] * 0.01, safe=safe, form=O.FORM_RECIP_AV)
+            assert bits_equal(x.cpu().numpy(), ex) and bits_equal(y.cpu().numpy(), ey), (n, off, safe)

@@ -46,6 +46,11 @@ def main():
     sky = out.clone()
     rec("sky2pix! 2xN safe=false (k_sky2pix_pairs)", timeit(lambda: pj.sky2pix_(g, sky, out, safe=False)), 32.0 * n, n / 1e6, "Mpts")
     rec("sky2pix! 2xN safe=true  (k_sky2pix_pairs)", timeit(lambda: pj.sky2pix_(g, sky, out, safe=True)), 32.0 * n, n / 1e6, "Mpts")
+    # SoA forms (two N-vectors in, two out): pix2sky(m, ivec, jvec) and the three sky2pix roundings
+    ip, jp = pix[:, 0].contiguous(), pix[:, 1].contiguous()
+    rec("pix2sky(i, j) SoA safe=true (k_pix2sky_soa)", timeit(lambda: pj.pix2sky(g, ip, jp, safe=True)), 32.0 * n, n / 1e6, "Mpts")
+    rec("sky2pix(ra, dec) SoA safe=true (k_sky2pix_soa)", timeit(lambda: pj.sky2pix(g, ip, jp, safe=True)), 32.0 * n, n / 1e6, "Mpts")
+    del ip, jp
     nb = 100_000_000
     small = pix[:nb].clone()
     small_out = torch.empty_like(small)
