@@ -999,7 +999,8 @@ static int sample_pairs_impl(const pxl_car_wcs* wcs_in, const int64_t shape_in[3
     if (n == 0) return PXL_OK;
     Sky2Pix s = sky2pix_setup(*wcs_in, shape_in[0], shape_in[1], 1, PXL_FORM_RECIP);
     int periodic = fabs((double)shape_in[0] * fabs(wcs_in->cdelt[0] * wcs_in->unit) - PXL_TWOPI_D) < 1e-8;
-    dim3 grid(stream_grid((n + PXL_SUNR - 1) / PXL_SUNR, 256));
+    const int unr = dtype == 4 ? PairsUnroll<float>::value : PairsUnroll<double>::value;
+    dim3 grid(stream_grid((n + unr - 1) / unr, 256));
     if (dtype == 4)
         hipLaunchKernelGGL((k_sample_pairs<float>), grid, dim3(256), 0, (hipStream_t)stream, s, (const float2*)pairs,
                            shape_in[0], shape_in[1], (int32_t)shape_in[2], src_row0, src_nrows, periodic, n,
