@@ -164,3 +164,32 @@ def test_scratch_pool_is_kept_and_released(env):
     assert torch.equal(first, again)
     torch.cuda.synchronize()
     assert lib.pxl_release_scratch() == 0
+
+
+def test_no_device_memory_leak(env):
+    """Plans (tables, zero page, exchange stream and events), one-shot entries and the unwind scratch pool give their
+    device memory back: free memory after a few hundred create/execute/destroy cycles is what it was before."""
+    pj, lib, dev = env
+    shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 400, dims=(2,))
+    shape_out, wcs_out = pj.fullsky_geometry(2 * math.pi / 600)
+    src = torch.randn((2, shape_in[1], shape_in[0]), dtype=torch.float64, device=dev)
+    dst = torch.empty((2, shape_out[1], shape_out[0]), dtype=torch.float64, device=dev)
+    pix = torch.rand((50_000, 2), dtype=torch.float64, device=dev) * 300
+    g = (shape_in[:2], wcs_in)
+
+    def cycle(n):
+        for _ in range(n):
+            plan = pj.ReprojectPlan(shape_in, wcs_in, shape_out, wcs_out, device=dev)
+            plan.execute(src, dst)
+            plan.close()
+            pj.pix2sky(g, pix, safe=True)
+        torch.cuda.synchronize()
+        assert lib.pxl_release_scratch() == 0
+
+    cycle(20)                                           # warm every lazy allocation (module load, pools, RNG state)
+    torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info(dev)
+    cycle(300)
+    torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info(dev)
+    assert abs(free1 - free0) <= 64 << 20, (free0, free1)
