@@ -17,8 +17,10 @@
  *   - Arrays are Julia column-major: maps are (nx, ny[, nc]) with RA the contiguous axis; coordinate
  *     batches are 2xN, i.e. interleaved (c1, c2) pairs (car_proj.jl:102-107).  Pixel coordinates are
  *     1-based Float64, angles are radians.
- *   - Arithmetic is IEEE double with NO fma contraction, op-for-op the reference's, so pix<->sky
- *     results are bit-identical to the reference CPU path.
+ *   - Arithmetic is IEEE double with NO fma contraction, written op-for-op from the reference's source.
+ *     What is TESTED: results are bit-identical to the CPU oracle (oracle/pixell_oracle.c); the oracle matches
+ *     every literal / data file of the reference's own tests at the reference's own tolerances (isapprox,
+ *     100 eps).  The reference itself (Julia) has never been executed next to this library: DESIGN.md 7.
  */
 #ifndef PIXELL_HIP_H
 #define PIXELL_HIP_H

@@ -219,7 +219,11 @@ int pxl_fullsky_geometry_cpu(double resx, double resy, int64_t* shape_io, pxl_ca
 }
 
 static double jl_sign(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : x); }
-static double jl_rad2deg(double x) { return x / (PXL_PI / 180); }  /* Base.rad2deg(z) = z / (pi/180) */
+/* Base.rad2deg(z::AbstractFloat) = z * (180 / oftype(z, pi))  (julia base/math.jl; the constant is the
+ * Float64 quotient 180/Float64(pi) = 57.29577951308232, formed once, then ONE multiply).  Round 1 restated it
+ * as z / (pi/180), which differs by 1 ulp on ~11 % of inputs; tests/test_oracle_reference.py keeps inputs where
+ * the two forms differ.  deg2rad(z) = z * (oftype(z, pi) / 180) likewise (tan_proj.jl:47,62).               */
+static double jl_rad2deg(double x) { return x * (180 / PXL_PI); }
 
 /* ---- geometry(W, bbox, res), enmap_geom.jl:77-108 (A5).  pos1 = bbox[:,1], pos2 = bbox[:,2],
  *      radians.  Returns -1/-2 for the two divisibility asserts (:82-85).                    */

@@ -21,7 +21,8 @@ def _jl_div(a: int, b: int) -> int:
 
 
 def _rad2deg(x: float) -> float:
-    return x / (PI / 180)       # Base.rad2deg
+    """Base.rad2deg(z::AbstractFloat) = z * (180 / oftype(z, pi)): one multiply by the Float64 constant 180/pi."""
+    return x * (180 / PI)
 
 
 def create_car_wcs(W, cdelt, crpix, crval):

@@ -377,3 +377,25 @@ def test_reproject_against_wcslib_plus_scipy(O, wcslib_vectors):
     r0, r1 = t["rows"]                                     # 1-based rows covered by the reference (poles skipped)
     ref = unhex(t["expected"], 1).reshape(r1 - r0 + 1, go["shape"][0])
     assert np.max(np.abs(out[r0 - 1:r1] - ref)) < 1e-11
+
+
+def test_rad2deg_follows_julia_base_multiply_form(O, pj):
+    """Base.rad2deg(z::AbstractFloat) = z * (180 / oftype(z, pi)) (julia base/math.jl) -- ONE multiply by the Float64
+    constant 180/pi.  The round-1 restatement z / (pi/180) differs by 1 ulp on ~11 % of inputs; geometry()
+    (enmap_geom.jl:100-102) must use the published form.  Inputs below are resolutions 2pi/n where the two forms
+    differ, so a regression to the division form fails here.  The constant is checked against its hex literal."""
+    k = 180 / math.pi
+    assert k.hex() == "0x1.ca5dc1a63c1f8p+5"
+    seen = 0
+    for n in (142, 198, 324, 597, 765, 1031, 1500):
+        res = 2 * math.pi / n
+        assert res * k != res / (math.pi / 180), "input no longer discriminates the two forms"
+        # a box whose RA midpoint is also a discriminating value
+        p1, p2 = (res * 7.0, -0.25), (res * 7.0 - res * 40, 0.25)
+        for geom in (lambda: O.geometry(p1, p2, res), lambda: pj.geometry([[p1[0], p2[0]], [p1[1], p2[1]]], res)):
+            shape, w = geom()
+            assert w.cdelt[0] == -res * k and w.cdelt[1] == res * k
+            mid = (p1[0] + p2[0]) / 2
+            assert w.crval[0] == mid * k and w.crval[1] == 0.0
+            seen += 1
+    assert seen == 14
