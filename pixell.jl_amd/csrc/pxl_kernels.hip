@@ -10,6 +10,7 @@
 //   pxl_maps.h           posmap, pixareamap                   pxl_tan.h        Gnomonic evaluators
 //   pxl_reproject.h      tables, gather + register-staged     pxl_reproject_dma.h  the LDS-DMA kernel (fast path)
 //   pxl_sample.h         CAR<->TAN reprojection, sampler      pxl_misc.h       FITS staging, synthetic data
+//   pxl_sample_binned.h  tile-binned scattered sampler (count / scan / scatter / gather / un-permute)
 // This file keeps the error plumbing and the extern "C" entry points.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared   (csrc/Makefile)
@@ -82,6 +83,7 @@ static int env_int(const char* name, int dflt) {
 #include "pxl_reproject.h"
 #include "pxl_reproject_dma.h"
 #include "pxl_sample.h"
+#include "pxl_sample_binned.h"
 #include "pxl_misc.h"
 #include "pxl_rccl.h"
 
@@ -1022,6 +1024,165 @@ int pxl_sample_car_bilinear_pairs_f32(const pxl_car_wcs* wcs_in, const int64_t s
                                       int64_t src_row0, int64_t src_nrows, int64_t n, const double* sky, float* out,
                                       void* stream) {
     return sample_pairs_impl(wcs_in, shape_in, pairs, src_row0, src_nrows, n, sky, out, stream, 4);
+}
+
+// ---- tile-binned scattered sampler (pxl_sample_binned.h): a plan owns the workspace (records, slots, values, tables)
+struct pxl_sample_plan {
+    pxl_car_wcs w;
+    int64_t nx, ny, nc, row0, nrows, nmax;
+    int periodic, device, dtype;
+    BinGrid g;
+    int pt;                 // points per thread of the count / scatter kernels: chunk = pt * 1024 points
+    int segs, vmajor, trips;
+    int64_t wmax;           // chunks at nmax
+    double2* rec; uint32_t* slot; void* val; uint16_t* cnt; uint32_t* off; uint32_t* seg; uint32_t* start;
+    size_t bytes;
+};
+
+static void sample_plan_free(pxl_sample_plan* pl) {
+    void* ptrs[] = {pl->rec, pl->slot, pl->val, pl->cnt, pl->off, pl->seg, pl->start};
+    for (void* q : ptrs) if (q) (void)hipFree(q);
+    delete pl;
+}
+
+int pxl_sample_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], int64_t src_row0, int64_t src_nrows,
+                           int64_t nmax, int elem_bytes, pxl_sample_plan** out) {
+    if (!out) return fail(PXL_EINVAL, "sample_plan_create: null plan pointer");
+    *out = nullptr;
+    if (!wcs_ok(wcs_in) || !shape_in) return fail(PXL_EINVAL, "sample_plan_create: invalid WCS/shape");
+    if (shape_in[0] < 1 || shape_in[1] < 1 || shape_in[2] < 1) return fail(PXL_EINVAL, "sample_plan_create: shapes must be positive");
+    if (shape_in[0] > 1000000000 || shape_in[1] > 1000000000) return fail(PXL_EINVAL, "sample_plan_create: axis too long (1e9 pixels)");
+    if (src_row0 < 0 || src_nrows < 0 || src_row0 + src_nrows > shape_in[1]) return fail(PXL_EINVAL, "sample_plan_create: source window outside the map");
+    if (elem_bytes != 4 && elem_bytes != 8) return fail(PXL_EINVAL, "sample_plan_create: elem_bytes must be 8 (Float64) or 4 (Float32)");
+    if (nmax < 1 || nmax > 0xffffffffLL) return fail(PXL_EINVAL, "sample_plan_create: nmax must be in [1, 2^32 - 1] (32-bit slots)");
+    pxl_sample_plan* pl = new (std::nothrow) pxl_sample_plan();
+    if (!pl) return fail(PXL_ENOMEM, "sample_plan_create: host allocation failed");
+    pl->w = *wcs_in;
+    pl->nx = shape_in[0]; pl->ny = shape_in[1]; pl->nc = shape_in[2];
+    pl->row0 = src_row0; pl->nrows = src_nrows; pl->nmax = nmax; pl->dtype = elem_bytes;
+    pl->periodic = fabs((double)pl->nx * fabs(wcs_in->cdelt[0] * wcs_in->unit) - PXL_TWOPI_D) < 1e-8;
+    hipError_t e = hipGetDevice(&pl->device);
+    if (e != hipSuccess) { delete pl; return fail(PXL_ENODEV, "hipGetDevice: %s", hipGetErrorString(e)); }
+    // tile grid: th rows x tw columns of about tile_kb, at most 8192 tiles (two u32 per tile in LDS)
+    const int64_t tile_bytes = (int64_t)env_int("PXL_SAMPLE_TILE_KB", 1536) * 1024;
+    int64_t th = env_int("PXL_SAMPLE_TH", 64);
+    if (th < 1) th = 1;
+    if (th > pl->ny) th = pl->ny;
+    int64_t tw, TX, TY;
+    for (;;) {
+        tw = tile_bytes / (th * elem_bytes);
+        if (tw < 64) tw = 64;
+        if (tw > pl->nx) tw = pl->nx;
+        TX = (pl->nx + tw - 1) / tw;
+        tw = (pl->nx + TX - 1) / TX;                  // even tiles
+        TY = (pl->ny + th - 1) / th;
+        if (TX * TY <= 8192) break;           // one u32 per tile in LDS, tot[] of k_bin_scan
+        th *= 2;
+        if (th > pl->ny) th = pl->ny;
+    }
+    pl->g.tw = (int32_t)tw; pl->g.th = (int32_t)th; pl->g.TX = (int32_t)TX; pl->g.TY = (int32_t)TY; pl->g.B = (int32_t)(TX * TY);
+    pl->g.inv_tw = 1.0f / (float)tw; pl->g.inv_th = 1.0f / (float)th;
+    pl->pt = env_int("PXL_SAMPLE_PT", 16);
+    pl->pt = pl->pt <= 8 ? 8 : (pl->pt <= 16 ? 16 : 32);      // chunk of 8, 16 or 32 Ki points (u16 counts)
+    pl->segs = env_int("PXL_SAMPLE_SEGS", 64);
+    if (pl->segs < 1) pl->segs = 1;
+    if (pl->segs > 1024) pl->segs = 1024;
+    pl->vmajor = env_int("PXL_SAMPLE_VMAJOR", 1) ? 1 : 0;
+    pl->trips = env_int("PXL_SAMPLE_TRIPS", 4);
+    if (pl->trips < 1) pl->trips = 1;
+    const int64_t P = (int64_t)pl->pt * PXL_BIN_THREADS;
+    pl->wmax = (nmax + P - 1) / P;
+    const size_t B = (size_t)pl->g.B;
+    struct { void** p; size_t bytes; } need[] = {
+        {(void**)&pl->rec, (size_t)nmax * 16}, {(void**)&pl->slot, (size_t)nmax * 4},
+        {(void**)&pl->val, (size_t)nmax * (size_t)pl->nc * (size_t)elem_bytes},
+        {(void**)&pl->cnt, (size_t)pl->wmax * B * 2}, {(void**)&pl->off, (size_t)pl->wmax * B * 4},
+        {(void**)&pl->seg, (size_t)pl->segs * B * 4}, {(void**)&pl->start, (B + 1) * 4}};
+    for (auto& q : need) {
+        e = hipMalloc(q.p, q.bytes);
+        if (e != hipSuccess) {
+            *q.p = nullptr;
+            const size_t want = q.bytes;
+            sample_plan_free(pl);
+            return fail(PXL_ENOMEM, "sample_plan_create: hipMalloc(%zu): %s", want, hipGetErrorString(e));
+        }
+        pl->bytes += q.bytes;
+    }
+    *out = pl;
+    return PXL_OK;
+}
+
+int64_t pxl_sample_plan_workspace_bytes(const pxl_sample_plan* pl) {
+    if (!pl) { fail(PXL_EINVAL, "sample_plan_workspace_bytes: null plan"); return -1; }
+    return (int64_t)pl->bytes;
+}
+
+int pxl_sample_plan_tiles(const pxl_sample_plan* pl, int32_t* tile_w, int32_t* tile_h, int32_t* ntiles) {
+    if (!pl) return fail(PXL_EINVAL, "sample_plan_tiles: null plan");
+    if (tile_w) *tile_w = pl->g.tw;
+    if (tile_h) *tile_h = pl->g.th;
+    if (ntiles) *ntiles = pl->g.B;
+    return PXL_OK;
+}
+
+int pxl_sample_plan_destroy(pxl_sample_plan* pl) {
+    if (pl) sample_plan_free(pl);
+    return PXL_OK;
+}
+
+}  // extern "C"
+template <typename T>
+static int sample_plan_execute_t(pxl_sample_plan* pl, const T* src, int64_t n, const double* sky, T* out, void* stream) {
+    if (!pl) return fail(PXL_EINVAL, "sample_plan_execute: null plan");
+    if ((int)sizeof(T) != pl->dtype) return fail(PXL_EINVAL, "sample_plan_execute: plan was created for %d-byte elements", pl->dtype);
+    if (n < 0 || n > pl->nmax) return fail(PXL_EINVAL, "sample_plan_execute: n outside [0, nmax]");
+    if (n > 0 && (!sky || !out || (!src && pl->nrows > 0))) return fail(PXL_EINVAL, "sample_plan_execute: null buffer");
+    if (((uintptr_t)sky & 15) != 0) return fail(PXL_EINVAL, "sample_plan_execute: 2xN buffer must be 16-byte aligned");
+    if (n == 0) return PXL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const Sky2Pix s = sky2pix_setup(pl->w, pl->nx, pl->ny, 1, PXL_FORM_RECIP);
+    const BinGrid g = pl->g;
+    const int64_t P = (int64_t)pl->pt * PXL_BIN_THREADS;
+    const int64_t W = (n + P - 1) / P;
+    const int B = g.B;
+    const int64_t NP = pl->vmajor ? 8 * ((W + 7) / 8) : W;
+    const int S = (int)std::min<int64_t>(pl->segs, NP);
+    const int64_t L = (NP + S - 1) / S;
+    const dim3 cgrid((unsigned)W), cblock(PXL_BIN_THREADS);
+    const dim3 sgrid((unsigned)((B + 255) / 256), (unsigned)S);
+    if (pl->pt == 8)       hipLaunchKernelGGL((k_bin_count<8>), cgrid, cblock, (size_t)B * 4, st, s, g, n, (const double2*)sky, pl->cnt);
+    else if (pl->pt == 16) hipLaunchKernelGGL((k_bin_count<16>), cgrid, cblock, (size_t)B * 4, st, s, g, n, (const double2*)sky, pl->cnt);
+    else                   hipLaunchKernelGGL((k_bin_count<32>), cgrid, cblock, (size_t)B * 4, st, s, g, n, (const double2*)sky, pl->cnt);
+    hipLaunchKernelGGL(k_bin_segsum, sgrid, dim3(256), 0, st, (const uint16_t*)pl->cnt, W, B, L, pl->vmajor, pl->seg);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, pl->seg, S, B, pl->start);
+    hipLaunchKernelGGL(k_bin_offsets, sgrid, dim3(256), 0, st, (const uint16_t*)pl->cnt, W, B, L, pl->vmajor,
+                       (const uint32_t*)pl->seg, (const uint32_t*)pl->start, pl->off);
+    int rc = check_launch("k_bin_count/scan");
+    if (rc) return rc;
+    if (pl->pt == 8)       hipLaunchKernelGGL((k_bin_scatter<8>), cgrid, cblock, (size_t)B * 4, st, s, g, n, (const double2*)sky,
+                                              (const uint32_t*)pl->off, pl->rec, pl->slot);
+    else if (pl->pt == 16) hipLaunchKernelGGL((k_bin_scatter<16>), cgrid, cblock, (size_t)B * 4, st, s, g, n, (const double2*)sky,
+                                              (const uint32_t*)pl->off, pl->rec, pl->slot);
+    else                   hipLaunchKernelGGL((k_bin_scatter<32>), cgrid, cblock, (size_t)B * 4, st, s, g, n, (const double2*)sky,
+                                              (const uint32_t*)pl->off, pl->rec, pl->slot);
+    rc = check_launch("k_bin_scatter");
+    if (rc) return rc;
+    const int64_t per_block = 256LL * PXL_BIN_SUNR * pl->trips;
+    const int64_t nblk8 = ((n + per_block - 1) / per_block + 7) / 8;
+    hipLaunchKernelGGL((k_sample_binned<T>), dim3((unsigned)(nblk8 * 8)), dim3(256), 0, st, src, pl->nx, pl->ny, (int32_t)pl->nc,
+                       pl->row0, pl->nrows, pl->periodic, n, (const double2*)pl->rec, (T*)pl->val, nblk8, pl->trips);
+    hipLaunchKernelGGL((k_bin_unpermute<T>), dim3(stream_grid((n + 3) / 4, 256)), dim3(256), 0, st, n, (int32_t)pl->nc,
+                       (const uint32_t*)pl->slot, (const T*)pl->val, out);
+    return check_launch("k_sample_binned");
+}
+
+extern "C" {
+int pxl_sample_plan_execute_f64(pxl_sample_plan* plan, const double* src, int64_t n, const double* sky2xN, double* out, void* stream) {
+    return sample_plan_execute_t<double>(plan, src, n, sky2xN, out, stream);
+}
+
+int pxl_sample_plan_execute_f32(pxl_sample_plan* plan, const float* src, int64_t n, const double* sky2xN, float* out, void* stream) {
+    return sample_plan_execute_t<float>(plan, src, n, sky2xN, out, stream);
 }
 
 int pxl_fits_decode_f64(const void* raw_be, double* dst, int64_t n, int bitpix, void* stream) {

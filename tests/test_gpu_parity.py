@@ -769,6 +769,62 @@ def test_sample_row_pair_layout(pj, O, dev):
         pj.SamplePairs(m, out=torch.empty(10, dtype=torch.float64, device=dev))
 
 
+def test_sample_binned_plan(pj, O, dev, monkeypatch):
+    """The tile-binned sampler (count / scan / scatter / tile-ordered gather / un-permute) gives the same bits as the
+    direct gather and as the oracle: Float64 and Float32, full maps and declination strips, periodic and partial-sky
+    maps, points far outside and non-finite ones, batch sizes around the chunk boundaries, every chunk size, both
+    chunk orders.  Tiles are forced small so that hundreds of tiles and partly empty ones are exercised."""
+    rng = np.random.default_rng(2024)
+    for pt, vmajor, tile_kb, th in ((8, 1, 4, 8), (16, 0, 16, 16), (32, 1, 1, 2)):
+        monkeypatch.setenv("PXL_SAMPLE_PT", str(pt))
+        monkeypatch.setenv("PXL_SAMPLE_VMAJOR", str(vmajor))
+        monkeypatch.setenv("PXL_SAMPLE_TILE_KB", str(tile_kb))
+        monkeypatch.setenv("PXL_SAMPLE_TH", str(th))
+        monkeypatch.setenv("PXL_SAMPLE_SEGS", "3")
+        for name, (shape, wcs) in geoms(pj).items():
+            if shape[0] * shape[1] > 4_000_000:
+                continue
+            nx, ny = shape
+            n = pt * 1024 * 3 + 77                     # three full chunks and a ragged fourth
+            sky = np.stack([2 * math.pi * rng.random(n) - math.pi, np.arcsin(2 * rng.random(n) - 1)], axis=1)
+            sky[:40, 0] += 4 * math.pi
+            sky[40] = (float("nan"), 0.1)
+            sky[41] = (0.2, float("inf"))
+            sky[42] = (float("-inf"), float("nan"))
+            d_sky = to_dev(sky, dev)
+            for nc, f32, (r0, nr) in ((1, False, (0, ny)), (3, False, (ny // 4, ny // 2)), (2, True, (0, ny))):
+                src = rng.normal(size=(nc, nr, nx))
+                if f32:
+                    src = src.astype(np.float32)
+                    expect = O.sample_bilinear_f32(wcs, (nx, ny, nc), src, sky, src_row0=r0, src_nrows=nr)
+                else:
+                    expect = O.sample_bilinear(wcs, (nx, ny, nc), src, sky, src_row0=r0, src_nrows=nr)
+                t = torch.from_numpy(src).to(dev)
+                m = pj.Enmap(t if nc > 1 else t[0], wcs)
+                plan = pj.SampleBinned(m, n + 5, src_rows=(r0, nr), full_shape=(nx, ny, nc))
+                assert plan.tiles[2] >= 1 and plan.workspace_bytes > 0
+                got = plan.sample(d_sky).cpu().numpy()
+                # a second, shorter batch through the same plan (n < nmax, ends inside a chunk)
+                got2 = plan.sample(d_sky[:pt * 1024 + 3]).cpu().numpy()
+                plan.close()
+                if f32:
+                    assert _f32_equal(np.nan_to_num(got), np.nan_to_num(expect)), (name, pt, nc, r0, nr)
+                    assert _f32_equal(np.nan_to_num(got2), np.nan_to_num(expect[:, :pt * 1024 + 3]))
+                else:
+                    assert _same_bits_or_nan(got, expect), (name, pt, nc, r0, nr)
+                    assert _same_bits_or_nan(got2, expect[:, :pt * 1024 + 3]), (name, pt, nc, r0, nr)
+                assert np.array_equal(np.isnan(got), np.isnan(expect))
+    # empty batch, argument checks
+    shape, wcs = pj.fullsky_geometry(1 * DEG)
+    m = pj.Enmap(torch.zeros((shape[1], shape[0]), dtype=torch.float64, device=dev), wcs)
+    plan = pj.SampleBinned(m, 100)
+    assert plan.sample(torch.empty((0, 2), dtype=torch.float64, device=dev)).shape == (1, 0)
+    with pytest.raises(RuntimeError):
+        plan.sample(torch.zeros((101, 2), dtype=torch.float64, device=dev))       # n > nmax
+    with pytest.raises(RuntimeError):
+        pj.SampleBinned(m, 0)
+
+
 def _same_bits_or_nan(a, b):
     """Bit equality where both are numbers, NaN where either is (the payload of a NaN is not part of the contract)."""
     a, b = np.asarray(a), np.asarray(b)
