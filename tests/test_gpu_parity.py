@@ -773,9 +773,16 @@ def test_sample_binned_plan(pj, O, dev, monkeypatch):
     """The tile-binned sampler (count / scan / scatter / tile-ordered gather / un-permute) gives the same bits as the
     direct gather and as the oracle: Float64 and Float32, full maps and declination strips, periodic and partial-sky
     maps, points far outside and non-finite ones, batch sizes around the chunk boundaries, every chunk size, both
-    chunk orders.  Tiles are forced small so that hundreds of tiles and partly empty ones are exercised."""
+    chunk orders, both gathers (direct taps out of L2; records in registers + source strips streamed through LDS by
+    LDS-DMA, one and several strips per tile).  Tiles are forced small so that hundreds of tiles and partly empty
+    ones are exercised."""
     rng = np.random.default_rng(2024)
-    for pt, vmajor, tile_kb, th in ((8, 1, 4, 8), (16, 0, 16, 16), (32, 1, 1, 2)):
+    for pt, vmajor, tile_kb, th, gather, lds_kb, rt in ((8, 1, 4, 8, 0, 144, 16), (16, 0, 16, 16, 0, 144, 16), (32, 1, 1, 2, 0, 144, 32),
+                                                        (16, 1, 4, 8, 1, 2, 32), (32, 0, 64, 32, 1, 144, 16), (8, 1, 1, 2, 1, 1, 16),
+                                                        (16, 1, 64, 32, 1, 16, 32)):
+        monkeypatch.setenv("PXL_SAMPLE_RT", str(rt))
+        monkeypatch.setenv("PXL_SAMPLE_GATHER", str(gather))
+        monkeypatch.setenv("PXL_SAMPLE_LDS_KB", str(lds_kb))
         monkeypatch.setenv("PXL_SAMPLE_PT", str(pt))
         monkeypatch.setenv("PXL_SAMPLE_VMAJOR", str(vmajor))
         monkeypatch.setenv("PXL_SAMPLE_TILE_KB", str(tile_kb))
