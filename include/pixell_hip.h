@@ -167,9 +167,10 @@ int pxl_reproject_plan_destroy(pxl_reproject_plan* plan);
  *      halo travels, then the rest.  The plan describes this rank's windows: src is its resident buffer
  *      ([nc,] src_nrows, nx) holding the rows it owns -- [own_row0, own_row0 + own_nrows), absolute -- with room
  *      for the halo rows around them; sends/recvs list absolute source rows (one RCCL message per component plane,
- *      straight from/into src: nothing is staged).  rccl_comm is the caller's ncclComm_t (one rank per GPU); the
- *      RCCL functions are looked up in the RCCL instance already loaded in the process (PXL_RCCL_LIB overrides),
- *      so this library has no link-time RCCL dependency.  The exchange runs on a stream owned by the plan,
+ *      straight from/into src: nothing is staged).  rccl_comm is the caller's ncclComm_t (one rank per GPU) or one made
+ *      by pxl_comm_init_rank; the RCCL functions are looked up in the RCCL instance already loaded in the process
+ *      (PXL_RCCL_LIB names it explicitly), never in a second instance loaded behind the caller's back, so this
+ *      library has no link-time RCCL dependency.  The exchange runs on a stream owned by the plan,
  *      ordered after everything queued on `stream` before the call; the function does not synchronise.
  *      With no transfers (one rank) it is build_tables + execute.  No reference counterpart.                    */
 typedef struct pxl_halo_xfer {
@@ -186,6 +187,19 @@ int pxl_reproject_sharded_step_f32(pxl_reproject_plan* plan, float* src, float* 
                                    int64_t own_row0, int64_t own_nrows,
                                    const pxl_halo_xfer* sends, int nsends, const pxl_halo_xfer* recvs, int nrecvs,
                                    void* rccl_comm, void* stream);
+
+/* ---- RCCL communicator for hosts that have no RCCL binding of their own (a Julia or C host; torch users pass
+ *      ProcessGroupNCCL's communicator instead).  Thin wrappers over ncclGetUniqueId / ncclCommInitRank /
+ *      ncclCommDestroy.  One rank calls pxl_comm_unique_id and distributes the PXL_COMM_ID_BYTES bytes to the others by
+ *      any means (file, MPI, socket); every rank then calls pxl_comm_init_rank (collective) with its HIP device current.
+ *      RCCL is looked up in the instance already loaded in the process, else PXL_RCCL_LIB, else the library loads
+ *      librccl.so itself -- and then pxl_reproject_sharded_step_* only accepts communicators created here (a
+ *      communicator means nothing to another RCCL instance).  pxl_comm_backend() says which instance is in use.     */
+#define PXL_COMM_ID_BYTES 128
+int pxl_comm_unique_id(void* id128);
+int pxl_comm_init_rank(const void* id128, int rank, int nranks, void** comm);
+int pxl_comm_destroy(void* comm);
+const char* pxl_comm_backend(void);
 
 /* one-shot convenience (creates a plan, executes, synchronises `stream`, destroys) */
 int pxl_reproject_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], const double* src,

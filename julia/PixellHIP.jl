@@ -192,5 +192,27 @@ function sharded_step!(dst::HIPArray{Float64}, plan::ReprojectPlan, src::HIPArra
     return dst
 end
 
+# ---- the RCCL communicator of a Julia host (no RCCL.jl needed): rank 0 makes the 128-byte id and hands it to the other
+#      ranks by any means (a file, MPI.jl, Sockets); every rank then joins with its HIP device current.
+struct PxlComm
+    handle::Ptr{Cvoid}
+end
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)                                    # PXL_COMM_ID_BYTES
+    GC.@preserve id check(ccall((:pxl_comm_unique_id, libpixell_hip), Cint, (Ptr{UInt8},), id))
+    return id
+end
+function comm_init_rank(id::Vector{UInt8}, rank::Integer, nranks::Integer)
+    length(id) == 128 || error("the communicator id is 128 bytes")
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve id check(ccall((:pxl_comm_init_rank, libpixell_hip), Cint, (Ptr{UInt8}, Cint, Cint, Ptr{Ptr{Cvoid}}),
+                                id, rank, nranks, h))
+    return PxlComm(h[])
+end
+sharded_step!(dst, plan, src, own_rows, sends, recvs, comm::PxlComm) = sharded_step!(dst, plan, src, own_rows, sends, recvs, comm.handle)
+comm_destroy(c::PxlComm) = check(ccall((:pxl_comm_destroy, libpixell_hip), Cint, (Ptr{Cvoid},), c.handle))
+comm_backend() = unsafe_string(ccall((:pxl_comm_backend, libpixell_hip), Cstring, ()))
+
 export HIPArray, posmap_device, reproject, reproject!, ReprojectPlan, sample_bilinear, HaloXfer, sharded_step!
+export PxlComm, comm_unique_id, comm_init_rank, comm_destroy, comm_backend
 end # module

@@ -60,6 +60,10 @@ SIGNATURES = {
     "pxl_reproject_plan_destroy": (C.c_int, [_P]),
     "pxl_reproject_sharded_step_f64": (C.c_int, [_P, _P, _P, _I64, _I64, _P, C.c_int, _P, C.c_int, _P, _P]),
     "pxl_reproject_sharded_step_f32": (C.c_int, [_P, _P, _P, _I64, _I64, _P, C.c_int, _P, C.c_int, _P, _P]),
+    "pxl_comm_unique_id": (C.c_int, [_P]),
+    "pxl_comm_init_rank": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "pxl_comm_destroy": (C.c_int, [_P]),
+    "pxl_comm_backend": (C.c_char_p, []),
     "pxl_reproject_car_bilinear_f64": (C.c_int, [_WP, _SHP, _P, _WP, _SHP, _P, _P]),
     "pxl_reproject_generic_bilinear_f64": (C.c_int, [_WP, C.c_int, _SHP, _P, _WP, C.c_int, _SHP, _P, _P]),
     "pxl_sample_car_bilinear_f64": (C.c_int, [_WP, _SHP, _P, _I64, _I64, _I64, _P, _P, _P]),

@@ -800,8 +800,11 @@ static int sharded_step_impl(pxl_reproject_plan* pl, void* src, void* dst, int64
     const bool exchange = nsends + nrecvs > 0;
     if (exchange) {
         if (!comm) return fail(PXL_EINVAL, "sharded_step: transfers listed but no RCCL communicator");
-        const RcclApi& nc = rccl_api();
+        const RcclApi& nc = rccl_api(false);
         if (!nc.ok) return fail(PXL_ENODEV, "sharded_step: RCCL entry points not available: %s", nc.where);
+        if (nc.own && !rccl_own_comm_has(comm))
+            return fail(PXL_ENODEV, "sharded_step: the communicator was not created by pxl_comm_init_rank, and the only RCCL instance "
+                                    "this library can see is one it loaded itself (%s): a foreign communicator belongs to another instance", nc.where);
         int nranks = 0, me = -1;
         if (nc.CommCount((ncclComm_t)comm, &nranks) != ncclSuccess || nc.CommUserRank((ncclComm_t)comm, &me) != ncclSuccess)
             return fail(PXL_EINVAL, "sharded_step: not a usable RCCL communicator");
@@ -867,6 +870,51 @@ static int sharded_step_impl(pxl_reproject_plan* pl, void* src, void* dst, int64
         }
     }
     return rc;
+}
+
+// ---- communicator helpers for hosts without an RCCL binding of their own (Julia, C): thin wrappers over
+// ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy, resolved through pxl_rccl.h
+int pxl_comm_unique_id(void* id128) {
+    if (!id128) return fail(PXL_EINVAL, "comm_unique_id: null buffer (PXL_COMM_ID_BYTES bytes)");
+    const RcclApi& nc = rccl_api(true);
+    if (!nc.ok) return fail(PXL_ENODEV, "comm_unique_id: RCCL not available: %s", nc.where);
+    static_assert(sizeof(ncclUniqueId) == PXL_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    ncclResult_t r = nc.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(PXL_EHIP, "comm_unique_id: ncclGetUniqueId: %s", nc.GetErrorString(r));
+    memcpy(id128, &id, sizeof id);
+    return PXL_OK;
+}
+
+int pxl_comm_init_rank(const void* id128, int rank, int nranks, void** comm) {
+    if (!id128 || !comm) return fail(PXL_EINVAL, "comm_init_rank: null argument");
+    *comm = nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(PXL_EINVAL, "comm_init_rank: rank %d outside [0, %d)", rank, nranks);
+    const RcclApi& nc = rccl_api(true);
+    if (!nc.ok) return fail(PXL_ENODEV, "comm_init_rank: RCCL not available: %s", nc.where);
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclComm_t c = nullptr;
+    ncclResult_t r = nc.CommInitRank(&c, nranks, id, rank);          // collective over the nranks callers; uses the current device
+    if (r != ncclSuccess) return fail(PXL_EHIP, "comm_init_rank: ncclCommInitRank: %s", nc.GetErrorString(r));
+    rccl_own_comm_add((void*)c);
+    *comm = (void*)c;
+    return PXL_OK;
+}
+
+int pxl_comm_destroy(void* comm) {
+    if (!comm) return PXL_OK;
+    if (!rccl_own_comm_erase(comm)) return fail(PXL_EINVAL, "comm_destroy: not a communicator created by pxl_comm_init_rank");
+    const RcclApi& nc = rccl_api(false);
+    if (!nc.ok) return fail(PXL_ENODEV, "comm_destroy: RCCL not available: %s", nc.where);
+    ncclResult_t r = nc.CommDestroy((ncclComm_t)comm);
+    if (r != ncclSuccess) return fail(PXL_EHIP, "comm_destroy: ncclCommDestroy: %s", nc.GetErrorString(r));
+    return PXL_OK;
+}
+
+const char* pxl_comm_backend(void) {
+    const RcclApi& nc = rccl_api(false);
+    return nc.where;
 }
 
 int pxl_reproject_sharded_step_f64(pxl_reproject_plan* plan, double* src, double* dst, int64_t own_row0, int64_t own_nrows,

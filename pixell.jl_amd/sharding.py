@@ -197,6 +197,42 @@ class DecStripReprojector(DecStripLayout):
         pg = self.group if self.group is not None else dist.distributed_c10d._get_default_group()
         return int(pg._get_backend(self.device)._comm_ptr())
 
+    def make_own_comm(self, ctrl_group=None):
+        """A communicator made through the library's own ABI (pxl_comm_unique_id / pxl_comm_init_rank) -- what a Julia
+        or C host does; here the 128-byte id travels over torch.distributed (any backend, e.g. a gloo control group).
+        Collective over the job's ranks.  Returns the ncclComm_t as an int; step_native(comm_ptr=...) takes it."""
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        ident = C.create_string_buffer(128)
+        if self.rank == 0:
+            with torch.cuda.device(self.device):
+                _lib.check(lib.pxl_comm_unique_id(ident))
+        box = [bytes(ident.raw)]
+        dist.broadcast_object_list(box, src=0, group=ctrl_group)
+        ident = C.create_string_buffer(box[0], 128)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.pxl_comm_init_rank(ident, self.rank, self.world, C.byref(h)))
+        self._own_comm = h
+        return int(h.value)
+
+    def close_own_comm(self):
+        from . import _lib
+        if getattr(self, "_own_comm", None):
+            _lib.check(_lib.load().pxl_comm_destroy(self._own_comm))
+            self._own_comm = None
+
+    def native_ready(self):
+        """Local pre-flight of the native step, before any rank posts anything: is the job's RCCL communicator
+        reachable from here?  Returns (ok, reason)."""
+        if not (self.sends or self.recvs):
+            return True, ""
+        try:
+            return (self.rccl_comm_ptr() != 0), "ProcessGroupNCCL has no communicator yet"
+        except Exception as e:                      # noqa: BLE001 -- reported by the caller
+            return False, "%s: %s" % (type(e).__name__, (str(e).splitlines() or [""])[0][:160])
+
     def step_native(self, src: torch.Tensor, dst: torch.Tensor, comm_ptr=None):
         """The same pass through the library's own sharded entry (pxl_reproject_sharded_step_*): RCCL send/recv
         issued by the library straight from/into the resident buffer (no staging copies, no Python in the loop),

@@ -54,3 +54,23 @@ def test_native_cpp_host(tmp_path):
         assert r.returncode == 0, (r.stdout, r.stderr)
         d = json.loads(r.stdout.strip().splitlines()[-1])
         assert d["native"] and d["kernel_ms"] > 0 and d["unity_err"] < 1e-13
+
+
+def test_native_host_makes_its_own_communicator(tmp_path):
+    """A host with no torch and no RCCL binding (what a Julia or C program is) shards through the C ABI alone: the
+    communicator comes from pxl_comm_unique_id / pxl_comm_init_rank (the library loads librccl itself), the sharded
+    step runs over it in loopback, and the strip is bit-identical to the unsharded map; a communicator the library
+    did not create is refused (tools/native/native_sharded.cpp)."""
+    import pixell_jl_amd as pj
+    libdir = os.path.dirname(pj.library_path())
+    exe = str(tmp_path / "native_sharded")
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tools", "native", "native_sharded.cpp"), "-L", libdir, "-lpixell_hip",
+           "-Wl,-rpath," + libdir, "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PXL_RCCL_LIB", None)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "native_sharded ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "loaded by libpixell_hip" in r.stdout          # the library's own RCCL instance, not one found in the process

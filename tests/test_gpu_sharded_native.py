@@ -39,10 +39,19 @@ def rccl():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("f32", [False, True])
-def test_sharded_step_loopback(pj, O, rccl, f32):
+@pytest.mark.parametrize("f32,own_comm", [(False, False), (True, False), (False, True)])
+def test_sharded_step_loopback(pj, O, rccl, f32, own_comm):
     dev, comm = rccl
     lib = pj.load_library()
+    made = None
+    if own_comm:            # the communicator a Julia / C host would make through the ABI (same RCCL instance as torch's here)
+        ident = C.create_string_buffer(128)
+        assert lib.pxl_comm_unique_id(ident) == 0, pj._lib.last_error()
+        made = C.c_void_p()
+        assert lib.pxl_comm_init_rank(ident, 0, 1, C.byref(made)) == 0, pj._lib.last_error()
+        assert lib.pxl_comm_init_rank(ident, 1, 1, C.byref(C.c_void_p())) == -22          # rank outside the communicator
+        comm = made.value
+        assert b"already loaded" in lib.pxl_comm_backend()
     # source 600 x 120, output 2x refined in RA and DEC; this "rank" owns source rows [41, 78) and output rows [80, 160)
     shape_in, wcs_in = (600, 120), pj.CarClenshawCurtis((-0.6, 0.5), (300.5, 60.0), (0.3, 0.0))
     shape_out, wcs_out = (1200, 240), pj.CarClenshawCurtis((-0.3, 0.25), (600.25, 120.3), (0.3, 0.0))
@@ -100,3 +109,6 @@ def test_sharded_step_loopback(pj, O, rccl, f32):
     torch.cuda.synchronize()
     assert np.array_equal(d_dst.cpu().numpy().view(np.int32 if f32 else np.int64), ref.view(np.int32 if f32 else np.int64))
     plan.close()
+    if made is not None:
+        assert lib.pxl_comm_destroy(made) == 0, pj._lib.last_error()
+        assert lib.pxl_comm_destroy(made) == -22                                           # already gone
