@@ -66,6 +66,7 @@ SIGNATURES = {
     "pxl_comm_backend": (C.c_char_p, []),
     "pxl_reproject_car_bilinear_f64": (C.c_int, [_WP, _SHP, _P, _WP, _SHP, _P, _P]),
     "pxl_reproject_generic_bilinear_f64": (C.c_int, [_WP, C.c_int, _SHP, _P, _WP, C.c_int, _SHP, _P, _P]),
+    "pxl_reproject_generic_last_tiles": (C.c_int, [C.POINTER(_I64), C.POINTER(_I64), _P]),
     "pxl_sample_car_bilinear_f64": (C.c_int, [_WP, _SHP, _P, _I64, _I64, _I64, _P, _P, _P]),
     "pxl_sample_car_bilinear_f32": (C.c_int, [_WP, _SHP, _P, _I64, _I64, _I64, _P, _P, _P]),
     "pxl_sample_pairs_elems": (_I64, [_SHP, _I64]),

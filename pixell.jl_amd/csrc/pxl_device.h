@@ -133,12 +133,18 @@ struct SrcViewT {
     int periodic;          // RA taps wrap modulo nx
 };
 using SrcView = SrcViewT<double>;
+// 1-based column of a periodic map: ((i - 1) mod nx) + 1.  Within one period either side it is a compare and an add
+// (safe sky2pix keeps x within half a period of the map centre); the 64-bit modulo (~100 instructions) only beyond.
+__device__ inline int64_t wrap_col(int64_t i, int64_t nx) {
+    if (i >= 1 - nx && i <= 2 * nx) { if (i > nx) i -= nx; else if (i < 1) i += nx; return i; }
+    i = (i - 1) % nx; if (i < 0) i += nx; return i + 1;
+}
 template <typename T>
 __device__ inline double tap(const SrcViewT<T>& m, int64_t i, int64_t j) {   // i, j 1-based
     if (j < 1 || j > m.ny) return 0.0;
     int64_t jr = j - 1 - m.row0;
     if (jr < 0 || jr >= m.nrows) return 0.0;
-    if (m.periodic) { i = (i - 1) % m.nx; if (i < 0) i += m.nx; i += 1; }
+    if (m.periodic) i = wrap_col(i, m.nx);
     else if (i < 1 || i > m.nx) return 0.0;
     return (double)m.plane[jr * m.nx + (i - 1)];
 }

@@ -311,14 +311,16 @@ int pxl_pix2sky_car_f64(const pxl_car_wcs* wcs, int64_t n, const double* pix, do
                            (const int32_t*)nullptr);
         return check_launch("k_pix2sky_pairs");
     }
+    // in-place (pix == sky) is fine, a partial overlap is not: every unwind form reads inputs other waves / rounds
+    // have not consumed yet while it stores (checked before ANY launch, the single-block form included)
+    const uintptr_t pa = (uintptr_t)pix, sa = (uintptr_t)sky, bytes = (uintptr_t)n * 16;
+    if (pa != sa && pa < sa + bytes && sa < pa + bytes) return fail(PXL_EINVAL, "pix2sky: pix and sky may alias exactly or not at all");
     if (n <= PXL_UWB_MAX) {       // small batch: everything in one launch of one block
         UwSrcPix2 src{c, (const double2*)pix, PXL_TWOPI_D, 0.0, 1.0 / PXL_TWOPI_D};
         hipLaunchKernelGGL((k_unwind_block<UwSrcPix2>), dim3(1), dim3(1024), 0, st, src, (double2*)sky, n, (const int32_t*)nullptr);
         return check_launch("k_unwind_block");
     }
     // safe=true on a long batch: fused rewind + verified scan; the multi-pass form only if its check fails
-    const uintptr_t pa = (uintptr_t)pix, sa = (uintptr_t)sky, bytes = (uintptr_t)n * 16;
-    if (pa != sa && pa < sa + bytes && sa < pa + bytes) return fail(PXL_EINVAL, "pix2sky: pix and sky may alias exactly or not at all");
     UnwindWs w;
     int rc = unwind_ws_alloc(n, 2, st, &w);
     if (rc) return rc;
@@ -459,7 +461,14 @@ int pxl_pixareamap_car_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64
     if (rc) return rc;
     if (nrows == 0) return PXL_OK;
     if (!area) return fail(PXL_EINVAL, "pixareamap: null output");
-    // rows go on grid.y (<= 65535 per launch)
+    if ((shape[0] & 1) == 0 && ((uintptr_t)area & 15) == 0 && env_int("PXL_AREA_ROWS", 0) == 0) {
+        // one contiguous chunk of the map per block (pairs of pixels, 16-byte stores)
+        const int64_t total = shape[0] / 2 * nrows;
+        hipLaunchKernelGGL(k_pixareamap_chunks, dim3((unsigned)((total + PXL_AREA_CHUNK - 1) / PXL_AREA_CHUNK)), dim3(256), 0,
+                           (hipStream_t)stream, car_affine(*wcs), shape[0], row0, nrows, area);
+        return check_launch("k_pixareamap_chunks");
+    }
+    // odd nx / unaligned map: one row per blockIdx.y (<= 65535 per launch)
     for (int64_t r = 0; r < nrows; r += 65535) {
         int64_t nr = (nrows - r < 65535) ? nrows - r : 65535;
         unsigned gx = (unsigned)std::max<int64_t>(1, ((shape[0] + 1) / 2 + 2047) / 2048);   // ~8 pairs per lane
@@ -945,6 +954,30 @@ int pxl_reproject_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shap
     return rc;
 }
 
+// diagnostics of the tiled generic reprojection: how many 64 x 16 tiles of the last call took the exact path
+static unsigned int* g_exact_tiles[64] = {};
+static int64_t g_generic_tiles[64] = {};
+static unsigned int* exact_tiles_counter(int* dev_out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    *dev_out = dev;
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    if (!g_exact_tiles[dev] && hipMalloc((void**)&g_exact_tiles[dev], 64) != hipSuccess) { (void)hipGetLastError(); g_exact_tiles[dev] = nullptr; }
+    return g_exact_tiles[dev];
+}
+
+int pxl_reproject_generic_last_tiles(int64_t* exact_tiles, int64_t* total_tiles, void* stream) {
+    if (!exact_tiles || !total_tiles) return fail(PXL_EINVAL, "generic_last_tiles: null argument");
+    int dev = 0;
+    unsigned int* c = exact_tiles_counter(&dev);
+    if (!c) return fail(PXL_ENODEV, "generic_last_tiles: no counter on this device");
+    unsigned int v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, c, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    *exact_tiles = v; *total_tiles = g_generic_tiles[dev];
+    return PXL_OK;
+}
+
 int pxl_reproject_generic_bilinear_f64(const pxl_car_wcs* wcs_in, int proj_in, const int64_t shape_in[3],
                                        const double* src, const pxl_car_wcs* wcs_out, int proj_out,
                                        const int64_t shape_out[2], double* dst, void* stream) {
@@ -966,8 +999,33 @@ int pxl_reproject_generic_bilinear_f64(const pxl_car_wcs* wcs_in, int proj_in, c
     if (proj_out == PXL_PROJ_TAN) p.out_tan = tan_setup(*wcs_out); else p.out_car = car_affine(*wcs_out);
     if (proj_in == PXL_PROJ_TAN) p.in_tan = tan_setup(*wcs_in);
     else p.in_car = sky2pix_setup(*wcs_in, p.nx, p.ny, 1, PXL_FORM_DIV);
-    hipLaunchKernelGGL(k_reproject_generic, dim3(stream_grid(p.nxo * p.nyo, 256)), dim3(256), 0, (hipStream_t)stream, p);
-    return check_launch("k_reproject_generic");
+    // PXL_GENERIC_EXACT=1: per-pixel evaluation of the coordinates (the definition; cross-check and fallback of the
+    // tiled kernel, which interpolates them per 64 x 16 tile within PXL_TILED_TOL pixel)
+    const int64_t gx = (p.nxo + 63) / 64, gy = (p.nyo + 15) / 16;
+    if (env_int("PXL_GENERIC_EXACT", 0) || gy > 65535) {
+        hipLaunchKernelGGL(k_reproject_generic, dim3(stream_grid(p.nxo * p.nyo, 256)), dim3(256), 0, (hipStream_t)stream, p);
+        return check_launch("k_reproject_generic");
+    }
+    int dev = 0;
+    p.exact_tiles = exact_tiles_counter(&dev);
+    if (p.exact_tiles) { HIP_TRY(hipMemsetAsync(p.exact_tiles, 0, 4, (hipStream_t)stream)); g_generic_tiles[dev] = gx * gy; }
+    // per-tile lattice (30 coordinate pairs) + flag from the library's stream-ordered scratch pool
+    const int64_t ntiles = gx * gy;
+    const size_t lat_bytes = (size_t)ntiles * (PXL_TNX * PXL_TNY) * sizeof(double2), total_bytes = lat_bytes + (size_t)ntiles * 4;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = nullptr;
+    hipMemPool_t pool = unwind_pool();
+    if (pool) HIP_TRY(hipMallocFromPoolAsync((void**)&ws, total_bytes, pool, st));
+    else HIP_TRY(hipMallocAsync((void**)&ws, total_bytes, st));
+    double2* lat = (double2*)ws;
+    int32_t* flag = (int32_t*)(ws + lat_bytes);
+    hipLaunchKernelGGL(k_generic_lattice, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, p, gx, ntiles, lat, flag);
+    hipLaunchKernelGGL(k_reproject_generic_tiled, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, (const double2*)lat, (const int32_t*)flag);
+    hipLaunchKernelGGL(k_reproject_generic_exact_tiles, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, (const int32_t*)flag);
+    int rc = check_launch("k_reproject_generic_tiled");
+    hipError_t fe = hipFreeAsync(ws, st);
+    if (fe != hipSuccess && rc == PXL_OK) rc = fail(PXL_EHIP, "reproject_generic: hipFreeAsync: %s", hipGetErrorString(fe));
+    return rc;
 }
 
 static int sample_impl(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], const void* src, int64_t src_row0,

@@ -51,3 +51,32 @@ __global__ __launch_bounds__(256) void k_pixareamap_car(CarAffine c, int64_t nx,
         else { area[o] = v; if (i + 1 < nx) area[o + 1] = v; }
     }
 }
+
+// pixareamap, contiguous form: the (nx, nrows) map is one 1-D stream of nx * nrows / 2 pairs; every block writes ONE
+// contiguous chunk of PXL_AREA_CHUNK pairs (it spans at most a few rows: the row value is recomputed when the row
+// changes).  Same idea as the 2xN evaluators (one contiguous chunk per block); needs nx even and a 16-byte aligned map.
+#define PXL_AREA_CHUNK 4096
+__device__ inline double pixarea_row(const CarAffine& c, double da, int64_t row0, int64_t jr) {
+    const double row = (double)(row0 + jr + 1);
+    double e0 = p2s_dec(c, row - 0.5), e1 = p2s_dec(c, row + 0.5);
+    double d1 = fmin(e0, e1), d2 = fmax(e0, e1);
+    d1 = fmax(-PXL_PI_D / 2, d1); d2 = fmin(PXL_PI_D / 2, d2);
+    return (sin(d2) - sin(d1)) * da;
+}
+__global__ __launch_bounds__(256) void k_pixareamap_chunks(CarAffine c, int64_t nx, int64_t row0, int64_t nrows,
+                                                           double* __restrict__ area) {
+    const double da = fabs(c.da);
+    const int64_t npr = nx / 2, total = npr * nrows;
+    const int64_t t0 = (int64_t)blockIdx.x * PXL_AREA_CHUNK;
+    int64_t jr = t0 / npr;
+    int64_t next = (jr + 1) * npr;                           // first pair of the next row
+    double v = pixarea_row(c, da, row0, jr);
+    double2* out = reinterpret_cast<double2*>(area);
+#pragma unroll 4
+    for (int it = 0; it < PXL_AREA_CHUNK / 256; ++it) {
+        const int64_t t = t0 + it * 256 + threadIdx.x;
+        if (t >= total) break;
+        while (t >= next) { ++jr; next += npr; v = pixarea_row(c, da, row0, jr); }
+        out[t] = make_double2(v, v);
+    }
+}

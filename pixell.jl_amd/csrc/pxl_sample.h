@@ -5,36 +5,222 @@
 // Per output pixel: (ra, dec) = pix2sky(out) [car_proj.jl:146-147 safe=false | tan_proj.jl:59-75];
 // (x, y) = sky2pix(in) [car_proj.jl:225-231 safe=true | tan_proj.jl:44-57]; 2x2 direct taps + lerp.
 // A sky point behind a Gnomonic source's tangent plane (cos c <= 0) is not on that map: it reads as 0.
-// FP64-transcendental bound (about ten libm calls per pixel), tolerance-checked rather than bit-exact.
+// k_reproject_generic evaluates the coordinates per pixel (about ten FP64 libm calls: transcendental bound);
+// k_reproject_generic_tiled interpolates them per tile with a checked error bound (HBM / gather bound).
+// Tolerance-checked rather than bit-exact either way.
 struct GenericParams {
     const double* src; double* dst;
     int64_t nx, ny, nxo, nyo;
     int32_t nc, periodic, proj_in, proj_out;
     CarAffine out_car; TanParams out_tan;
     Sky2Pix in_car; TanParams in_tan;
+    unsigned int* exact_tiles;         // diagnostics: counts the tiles that took the exact path (may be null)
 };
+// exact source coordinates of output pixel (i, j) (1-based, may lie outside the output map): the evaluators of the
+// reference, per pixel.  *visible: the sky point is in front of a Gnomonic source's tangent plane.
+__device__ inline void generic_coords(const GenericParams& p, double i, double j, double* x, double* y, bool* visible) {
+    double ra, dec;
+    if (p.proj_out == PXL_PROJ_TAN) tan_pix2sky(p.out_tan, i, j, &ra, &dec);
+    else { ra = p2s_ra(p.out_car, i); dec = p2s_dec(p.out_car, j); }
+    *visible = true;
+    if (p.proj_in == PXL_PROJ_TAN) {
+        tan_sky2pix(p.in_tan, ra, dec, x, y);
+        *visible = (p.in_tan.sd0 * sin(dec) + cos(dec) * cos(ra - p.in_tan.a0) * p.in_tan.cd0) > 0.0;
+    } else { *x = s2p_x(p.in_car, ra); *y = s2p_y(p.in_car, dec); }
+}
+__device__ inline void generic_store(const GenericParams& p, int64_t t, double x, double y, bool visible) {
+    const int64_t total = p.nxo * p.nyo;
+    const bool fin = isfinite(x) && isfinite(y);
+    int32_t i0, j0; double fx, fy;
+    split_cell(x, &i0, &fx);
+    split_cell(y, &j0, &fy);
+    // interior cell (all four taps inside the map, or wrapping once on a periodic one): two row offsets, no per-tap checks
+    const bool jin = j0 >= 1 && j0 < p.ny;
+    const bool iin = p.periodic ? (i0 >= 0 && i0 <= p.nx) : (i0 >= 1 && i0 < p.nx);
+    if (visible && fin && jin && iin) {
+        const int64_t ia = (i0 >= 1 ? i0 : p.nx) - 1, ib = (i0 < p.nx ? i0 + 1 : 1) - 1;       // 0-based columns of i0, i0 + 1
+        const int64_t ra = (int64_t)(j0 - 1) * p.nx, rb = ra + p.nx;
+        for (int c = 0; c < p.nc; ++c) {
+            const double* pl = p.src + (int64_t)c * p.nx * p.ny;
+            const double top = (1 - fx) * pl[ra + ia] + fx * pl[ra + ib];
+            const double bot = (1 - fx) * pl[rb + ia] + fx * pl[rb + ib];
+            p.dst[(int64_t)c * total + t] = (1 - fy) * top + fy * bot;
+        }
+        return;
+    }
+    for (int c = 0; c < p.nc; ++c) {
+        SrcView m{p.src + (int64_t)c * p.nx * p.ny, p.nx, p.ny, 0, p.ny, p.periodic};
+        double v = visible ? bilerp_cells(m, i0, fx, j0, fy) : 0.0;
+        p.dst[(int64_t)c * total + t] = fin ? v : __builtin_nan("");
+    }
+}
 __global__ __launch_bounds__(256) void k_reproject_generic(GenericParams p) {
     const int64_t total = p.nxo * p.nyo;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
         const int64_t jr = t / p.nxo, i = t - jr * p.nxo;
-        double ra, dec;
-        if (p.proj_out == PXL_PROJ_TAN) tan_pix2sky(p.out_tan, (double)(i + 1), (double)(jr + 1), &ra, &dec);
-        else { ra = p2s_ra(p.out_car, (double)(i + 1)); dec = p2s_dec(p.out_car, (double)(jr + 1)); }
-        double x, y;
-        bool visible = true;
-        if (p.proj_in == PXL_PROJ_TAN) {
-            tan_sky2pix(p.in_tan, ra, dec, &x, &y);
-            visible = (p.in_tan.sd0 * sin(dec) + cos(dec) * cos(ra - p.in_tan.a0) * p.in_tan.cd0) > 0.0;
-        } else { x = s2p_x(p.in_car, ra); y = s2p_y(p.in_car, dec); }
-        const bool fin = isfinite(x) && isfinite(y);
-        int32_t i0, j0; double fx, fy;
-        split_cell(x, &i0, &fx);
-        split_cell(y, &j0, &fy);
-        for (int c = 0; c < p.nc; ++c) {
-            SrcView m{p.src + (int64_t)c * p.nx * p.ny, p.nx, p.ny, 0, p.ny, p.periodic};
-            double v = visible ? bilerp_cells(m, i0, fx, j0, fy) : 0.0;
-            p.dst[(int64_t)c * total + t] = fin ? v : __builtin_nan("");
+        double x, y; bool visible;
+        generic_coords(p, (double)(i + 1), (double)(jr + 1), &x, &y, &visible);
+        generic_store(p, t, x, y, visible);
+    }
+}
+
+// ---- the same operator with the coordinate map interpolated per output tile (what python-pixell does for non-
+// separable reprojections, and the only way off the transcendental roof: ~10 FP64 libm calls per pixel above).
+// Tile = 64 x 16 output pixels.  The exact (x, y) of the reference's
+// evaluators is computed on a 6 x 5 lattice of the tile (36 evaluations per 1024 pixels with the check points) and
+// every pixel takes the tensor-product Lagrange interpolant of degree 5 x 4 (error ~ h^6 f^(6) / 6!: 1e-14 pixel at
+// 0.5 arcmin, below the rounding noise of the exact evaluation).  The interpolant is CHECKED per tile against exact evaluations at six off-lattice points: if either
+// coordinate is off by more than PXL_TILED_TOL pixel anywhere, or a lattice point is non-finite or behind the
+// tangent plane (the rewind jump of a periodic source and the Gnomonic horizon land here), the whole tile takes the
+// exact per-pixel path -- so the result differs from k_reproject_generic by at most PXL_TILED_TOL pixel in the
+// sampling position, i.e. ~1e-10 x the local map gradient in value, inside the reference's own Gnomonic tolerance
+// (test/test_geometry.jl:116-119: 1e-9).
+// 1e-10 pixel: the per-pixel evaluation itself carries ~1e-11 pixel of libm rounding noise at x ~ 2e4 (ulp 3.6e-12,
+// a few ulp through atan2 / asin / division by the pixel size), so a tighter check fails on noise, not on the interpolant
+#define PXL_TILED_TOL 1e-10
+#define PXL_TNX 6
+#define PXL_TNY 5
+// Lagrange basis on the N equispaced nodes 0, h, ..., (N-1) h.  The denominators prod_{c != a} (a - c) h are
+// constants (+-120, 24, 12 x h^5 for N = 6; 24, 6, 4 x h^4 for N = 5): no division in the kernel.
+template <int N>
+__device__ inline void lagrange_weights(double u, double h, double* w) {
+    double d[N];
+#pragma unroll
+    for (int c = 0; c < N; ++c) d[c] = u - c * h;
+    double hp = 1.0;
+#pragma unroll
+    for (int c = 1; c < N; ++c) hp *= h;
+    const double rh = 1.0 / hp;                                   // one division per call (h^(N-1))
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+        double num = 1.0;
+        int k = 1;                                                // prod_{c != a} (a - c), an integer
+#pragma unroll
+        for (int c = 0; c < N; ++c)
+            if (c != a) { num *= d[c]; k *= (a - c); }
+        w[a] = num * (rh / (double)k);
+    }
+}
+// Two launches.  k_generic_lattice: every tile's 30 lattice points + 6 check points, all tiles in parallel (one wave
+// per tile; the ~10 libm calls per point are the expensive part and no pixel waits behind them); per tile it leaves the
+// lattice coordinates and a flag (1 = the interpolant failed its check or a point is non-finite / not visible).
+// k_reproject_generic_tiled: one block per tile, 4 pixels per thread, no LDS and no barrier: the tile's lattice is
+// wave-uniform data.
+// The pixels of a tile sit at integer positions 0..63 x 0..15 of the lattice's coordinate system, the same in every
+// tile: their Lagrange weights are compile-time tables.
+struct TileWeights { double wx[64][PXL_TNX]; double wy[16][PXL_TNY]; };
+constexpr double lag_w(int n, double h, double u, int a) {
+    double num = 1.0, den = 1.0;
+    for (int c = 0; c < n; ++c)
+        if (c != a) { num *= (u - c * h); den *= ((a - c) * h); }
+    return num / den;
+}
+constexpr TileWeights make_tile_weights() {
+    TileWeights t{};
+    for (int u = 0; u < 64; ++u)
+        for (int a = 0; a < PXL_TNX; ++a) t.wx[u][a] = lag_w(PXL_TNX, 63.0 / (PXL_TNX - 1), (double)u, a);
+    for (int v = 0; v < 16; ++v)
+        for (int b = 0; b < PXL_TNY; ++b) t.wy[v][b] = lag_w(PXL_TNY, 15.0 / (PXL_TNY - 1), (double)v, b);
+    return t;
+}
+__constant__ TileWeights c_tile_weights = make_tile_weights();
+
+__global__ __launch_bounds__(256) void k_generic_lattice(GenericParams p, int64_t ntx, int64_t ntiles,
+                                                         double2* __restrict__ lat, int32_t* __restrict__ flag) {
+    __shared__ double lx[4][PXL_TNX * PXL_TNY], ly[4][PXL_TNX * PXL_TNY];
+    __shared__ int bad[4];
+    const int w = threadIdx.x >> 6, k = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + w;
+    const bool live = tile < ntiles;
+    const int64_t ti0 = live ? (tile % ntx) * 64 : 0, tj0 = live ? (tile / ntx) * 16 : 0;
+    const double hx = 63.0 / (PXL_TNX - 1), hy = 15.0 / (PXL_TNY - 1);
+    if (k == 0) bad[w] = 0;
+    __syncthreads();
+    double ex = 0.0, ey = 0.0, cu = 0.0, cv = 0.0;
+    bool is_check = false;
+    if (live && k < PXL_TNX * PXL_TNY) {
+        const int a = k % PXL_TNX, b = k / PXL_TNX;
+        bool vis;
+        generic_coords(p, (double)(ti0 + 1) + a * hx, (double)(tj0 + 1) + b * hy, &ex, &ey, &vis);
+        lx[w][k] = ex; ly[w][k] = ey;
+        lat[tile * (PXL_TNX * PXL_TNY) + k] = make_double2(ex, ey);
+        if (!vis || !isfinite(ex) || !isfinite(ey)) bad[w] = 1;
+    } else if (live && k >= 32 && k < 38) {
+        const double us[6] = {6.3, 31.5, 56.7, 18.9, 44.1, 59.85}, vs[6] = {1.9, 7.5, 13.1, 11.2, 3.7, 14.1};
+        cu = us[k - 32]; cv = vs[k - 32];
+        bool vis;
+        generic_coords(p, (double)(ti0 + 1) + cu, (double)(tj0 + 1) + cv, &ex, &ey, &vis);
+        is_check = true;
+        if (!vis || !isfinite(ex) || !isfinite(ey)) bad[w] = 1;
+    }
+    __syncthreads();
+    if (is_check && !bad[w]) {
+        double wx[PXL_TNX], wy[PXL_TNY];
+        lagrange_weights<PXL_TNX>(cu, hx, wx);
+        lagrange_weights<PXL_TNY>(cv, hy, wy);
+        double sx = 0.0, sy = 0.0;
+        for (int b = 0; b < PXL_TNY; ++b)
+            for (int a = 0; a < PXL_TNX; ++a) {
+                const double ww = wx[a] * wy[b];
+                sx = __builtin_fma(ww, lx[w][b * PXL_TNX + a], sx);
+                sy = __builtin_fma(ww, ly[w][b * PXL_TNX + a], sy);
+            }
+        if (!(fabs(sx - ex) <= PXL_TILED_TOL && fabs(sy - ey) <= PXL_TILED_TOL)) bad[w] = 1;
+    }
+    __syncthreads();
+    if (live && k == 0) {
+        flag[tile] = bad[w];
+        if (bad[w] && p.exact_tiles) atomicAdd(p.exact_tiles, 1u);
+    }
+}
+// the tiles whose interpolant failed its check: exact evaluation per pixel (a launch of its own, so that the hot
+// kernel below carries no libm code; blocks of tiles that passed exit at once)
+__global__ __launch_bounds__(256) void k_reproject_generic_exact_tiles(GenericParams p, const int32_t* __restrict__ flag) {
+    const int64_t tile = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (!flag[tile]) return;
+    const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63), jr0 = (int64_t)blockIdx.y * 16 + (threadIdx.x >> 6);
+    if (i >= p.nxo) return;
+    for (int q = 0; q < 4; ++q) {
+        const int64_t jr = jr0 + 4 * q;
+        if (jr < p.nyo) {
+            double x, y; bool visible;
+            generic_coords(p, (double)(i + 1), (double)(jr + 1), &x, &y, &visible);
+            generic_store(p, jr * p.nxo + i, x, y, visible);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_reproject_generic_tiled(GenericParams p, const double2* __restrict__ lat,
+                                                                 const int32_t* __restrict__ flag) {
+    const int64_t tile = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const int64_t ti0 = (int64_t)blockIdx.x * 64, tj0 = (int64_t)blockIdx.y * 16;      // 0-based tile origin
+    const int tid = threadIdx.x;
+    const int cx = tid & 63, ry = tid >> 6;
+    const int64_t i = ti0 + cx;
+    if (i >= p.nxo) return;
+    if (flag[tile]) return;                      // k_reproject_generic_exact_tiles does this tile
+    const double2* L = lat + tile * (PXL_TNX * PXL_TNY);
+    double wx[PXL_TNX];
+#pragma unroll
+    for (int a = 0; a < PXL_TNX; ++a) wx[a] = c_tile_weights.wx[cx][a];
+    // column-interpolated lattice: one value per lattice row, reused by this thread's four rows
+    double colx[PXL_TNY], coly[PXL_TNY];
+#pragma unroll
+    for (int b = 0; b < PXL_TNY; ++b) {
+        double sx = 0.0, sy = 0.0;
+#pragma unroll
+        for (int a = 0; a < PXL_TNX; ++a) { const double2 v = L[b * PXL_TNX + a]; sx = __builtin_fma(wx[a], v.x, sx); sy = __builtin_fma(wx[a], v.y, sy); }
+        colx[b] = sx; coly[b] = sy;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = ry + 4 * q;
+        const int64_t jr = tj0 + r;
+        if (jr < p.nyo) {
+            double x = 0.0, y = 0.0;
+#pragma unroll
+            for (int b = 0; b < PXL_TNY; ++b) { const double wy = c_tile_weights.wy[r][b]; x = __builtin_fma(wy, colx[b], x); y = __builtin_fma(wy, coly[b], y); }
+            generic_store(p, jr * p.nxo + i, x, y, true);
         }
     }
 }
@@ -48,10 +234,6 @@ __global__ __launch_bounds__(256) void k_reproject_generic(GenericParams p) {
 #ifndef PXL_SUNR
 #define PXL_SUNR 4
 #endif
-__device__ inline int64_t wrap_col(int64_t i, int64_t nx) {          // 1-based column of a periodic map
-    if (i >= 1 - nx && i <= 2 * nx) { if (i > nx) i -= nx; else if (i < 1) i += nx; return i; }
-    i = (i - 1) % nx; if (i < 0) i += nx; return i + 1;
-}
 template <typename T>
 __global__ __launch_bounds__(256) void k_sample_bilinear(Sky2Pix s, const T* __restrict__ src, int64_t nx,
                                                          int64_t ny, int32_t nc, int64_t row0, int64_t nrows,

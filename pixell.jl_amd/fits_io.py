@@ -175,18 +175,35 @@ def _want_dtype(bitpix, dtype):
     return want
 
 
-def _flip_u_if_iau(h, out, comps, verbose):
-    """IAU <-> COSMO (enmap.jl:178-195,206-211): flip U (third Stokes plane) when the file says POLCCONV = IAU.
-    comps = 0-based file component held by each plane of `out`."""
-    if "STOKES" in [v for v in h.values() if isinstance(v, str)] and h.get("POLCCONV", "COSMO") == "IAU" and out.dim() == 3:
+def _resolve_polcconv(h, out, comps, verbose, mode="reference"):
+    """IAU -> COSMO sign flip of a polarisation map, enmap.jl:178-195 called from read_map (:203-209): only when some
+    header value is "STOKES" and POLCCONV == "IAU", and only on the axis i whose CTYPEi == "STOKES".
+    mode="reference" (default) reproduces what the reference DOES: `signs = ones(1, 1, 3); signs[signs_size] .= -1`
+    with signs_size = [1, 1, 3] is linear indexing, so planes 1 AND 3 (I and U) change sign; mode="u_only" flips only
+    U (the physical IAU <-> COSMO convention, probably what was meant).  comps = 0-based file component of each plane
+    of `out` (a selection along the Stokes axis selects the same entries of `signs`, :189-190)."""
+    if "STOKES" not in [v for v in h.values() if isinstance(v, str)] or h.get("POLCCONV", "COSMO") != "IAU":
+        return
+    if mode not in ("reference", "u_only"):
+        raise ValueError("polcconv must be 'reference' or 'u_only'")
+    naxis = int(h["NAXIS"])
+    for i in range(1, naxis + 1):
+        if h.get("CTYPE%d" % i, "") != "STOKES":
+            continue
+        if i != 3 or out.dim() != 3:
+            raise NotImplementedError("STOKES on axis %d: only the component axis (3) of an (nx, ny, nc) map is supported" % i)
+        if int(h["NAXIS3"]) != 3:
+            raise ValueError("POLCCONV=IAU with %d Stokes planes: the reference's (1, 1, 3) sign array does not broadcast "
+                             "(DimensionMismatch there)" % int(h["NAXIS3"]))
         if verbose:
-            print("convert to IAU: flip U")
+            print("convert to IAU: flip U in axis %d" % i)
+        flip = (0, 2) if mode == "reference" else (2,)
         for plane, c in enumerate(comps):
-            if c == 2:
+            if c in flip:
                 out[plane].neg_()
 
 
-def read_map_rows(path, row0, nrows, device="cuda", comps=None, dtype=None, verbose=False):
+def read_map_rows(path, row0, nrows, device="cuda", comps=None, dtype=None, verbose=False, polcconv="reference"):
     """Rows [row0, row0 + nrows) (0-based) of every component of a FITS map, straight into HBM: the declination
     strip of one rank of a sharded job (rows are contiguous on disk, so only those bytes are read).  Returns
     (tensor ([nc,] nrows, nx), full Julia shape, WCS of the FULL map) -- windows into the full geometry, like
@@ -213,11 +230,11 @@ def read_map_rows(path, row0, nrows, device="cuda", comps=None, dtype=None, verb
         else:
             merged.append(sp)
     _read_spans(path, merged, out, bitpix, dev)
-    _flip_u_if_iau(h, out, comps, verbose)
+    _resolve_polcconv(h, out, comps, verbose, polcconv)
     return out, tuple(dims), wcs_from_header(h)
 
 
-def read_map(path, device="cuda", sel=None, verbose=False, dtype=None):
+def read_map(path, device="cuda", sel=None, verbose=False, dtype=None, polcconv="reference"):
     """read_map(path; sel) -> Enmap on the device.  sel = (sel_x, sel_y[, sel_c]) with the 1-based inclusive
     selections of geometry.slice_geometry (e.g. ((11, 20), (21, 40), (1, 2)) for 11:20, 21:40, 1:2).
     The element type follows the file (BITPIX -64 -> Float64, -32 -> Float32, like the reference's read);
@@ -236,11 +253,11 @@ def read_map(path, device="cuda", sel=None, verbose=False, dtype=None):
     if sel is None or whole_rows:
         row0, nrows = (0, ny) if sel is None else (ry.first - 1, ry.length)
         comps = None if rc is None else list(range(rc.first - 1, rc.last))
-        data, _, wcs = read_map_rows(path, row0, nrows, device=device, comps=comps, dtype=dtype, verbose=verbose)
+        data, _, wcs = read_map_rows(path, row0, nrows, device=device, comps=comps, dtype=dtype, verbose=verbose, polcconv=polcconv)
         if sel is not None:
             _, wcs = slice_geometry((nx, ny), wcs, rx, ry)
         return Enmap(data, wcs)
-    data, _, wcs = read_map_rows(path, 0, ny, device=device, dtype=dtype, verbose=verbose)
+    data, _, wcs = read_map_rows(path, 0, ny, device=device, dtype=dtype, verbose=verbose, polcconv=polcconv)
     return Enmap(data, wcs).getindex(*sel)
 
 
@@ -260,8 +277,10 @@ def _card(key, value, comment=""):
     return ("%-80s" % card)[:80]
 
 
-def write_map(path, m: Enmap):
-    """write_map(fname, emap) -- enmap.jl:225-237: BITPIX -64 primary HDU + the CAR WCS cards, degrees."""
+def write_map(path, m: Enmap, extra_cards=()):
+    """write_map(fname, emap) -- enmap.jl:225-237: BITPIX -64 primary HDU + the CAR WCS cards, degrees.
+    extra_cards: (key, value) pairs appended to the header (e.g. CTYPE3 / POLCCONV of a polarisation map; the
+    reference writes none)."""
     data = m.data
     if data.dtype not in (torch.float64, torch.float32) or not data.is_contiguous():
         raise TypeError("write_map needs a contiguous float64 or float32 map")
@@ -278,7 +297,8 @@ def write_map(path, m: Enmap):
     cards += [_card("WCSAXES", 2), _card("CRPIX1", wcs.crpix[0]), _card("CRPIX2", wcs.crpix[1]),
               _card("CDELT1", wcs.cdelt[0] * scale), _card("CDELT2", wcs.cdelt[1] * scale),
               _card("CUNIT1", "deg"), _card("CUNIT2", "deg"), _card("CTYPE1", "RA---CAR"), _card("CTYPE2", "DEC--CAR"),
-              _card("CRVAL1", wcs.crval[0] * scale), _card("CRVAL2", wcs.crval[1] * scale), "%-80s" % "END"]
+              _card("CRVAL1", wcs.crval[0] * scale), _card("CRVAL2", wcs.crval[1] * scale)]
+    cards += [_card(k, v) for k, v in extra_cards] + ["%-80s" % "END"]
     header = "".join(cards)
     header += " " * (-len(header) % BLOCK)
     n = data.numel()

@@ -124,3 +124,27 @@ def test_header_units(pj):
         assert abs(pj.wcs_from_header(h2).unit - unit) <= 1e-18 * max(1.0, unit)
     with pytest.raises(AssertionError):
         pj.wcs_from_header(dict(h, CUNIT1="deg", CUNIT2="rad"))
+
+
+@pytest.mark.gpu
+def test_polcconv_iau_follows_the_reference(pj, tmp_path):
+    """POLCCONV = IAU files (enmap.jl:178-195, :203-209): the reference multiplies by `signs` built with
+    `signs[signs_size] .= -1`, signs_size = [1, 1, 3] -- linear indices 1 and 3, i.e. planes I and U change sign.
+    The default reproduces that; polcconv="u_only" is the physical convention.  Gated on CTYPE3 == "STOKES"."""
+    import math
+    import torch
+    shape, wcs = pj.fullsky_geometry(2 * math.pi / 32, dims=(3,))
+    m = pj.Enmap(torch.randn((3, shape[1], shape[0]), dtype=torch.float64, device="cuda:0"), wcs)
+    iau, cosmo, notstokes = (str(tmp_path / n) for n in ("iau.fits", "cosmo.fits", "other.fits"))
+    pj.write_map(iau, m, extra_cards=[("CTYPE3", "STOKES"), ("POLCCONV", "IAU")])
+    pj.write_map(cosmo, m, extra_cards=[("CTYPE3", "STOKES"), ("POLCCONV", "COSMO")])
+    pj.write_map(notstokes, m, extra_cards=[("CTYPE3", "FREQ"), ("POLCCONV", "IAU")])
+    ref = pj.read_map(iau, device="cuda:0")
+    assert torch.equal(ref.data[0], -m.data[0]) and torch.equal(ref.data[1], m.data[1]) and torch.equal(ref.data[2], -m.data[2])
+    phys = pj.read_map(iau, device="cuda:0", polcconv="u_only")
+    assert torch.equal(phys.data[0], m.data[0]) and torch.equal(phys.data[1], m.data[1]) and torch.equal(phys.data[2], -m.data[2])
+    assert torch.equal(pj.read_map(cosmo, device="cuda:0").data, m.data)
+    assert torch.equal(pj.read_map(notstokes, device="cuda:0").data, m.data)        # no axis is STOKES: untouched
+    # a selection along the Stokes axis selects the same signs (enmap.jl:189-190): planes 2:3 -> (+Q, -U)
+    sub = pj.read_map(iau, device="cuda:0", sel=(None, None, (2, 3)))
+    assert torch.equal(sub.data[0], m.data[1]) and torch.equal(sub.data[1], -m.data[2])

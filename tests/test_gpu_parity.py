@@ -533,6 +533,29 @@ def test_generic_reproject_car_tan(pj, O, dev, literals):
         assert np.isfinite(got).all()
         assert np.abs(got - exp).max() < 1e-9, (p_in, p_out, np.abs(got - exp).max())
         assert np.abs(exp).max() > 0.1                      # the maps overlap: this is not a comparison of zeros
+    # the tiled kernel (coordinates interpolated per 64 x 16 tile, checked to 1e-11 pixel) against the per-pixel one
+    # (PXL_GENERIC_EXACT=1) and the oracle: a periodic full-sky CAR source seen from a TAN patch that straddles the
+    # RA = 180 deg seam (tiles across the rewind jump must fall back to exact evaluation), at 0.5 and at 20 arcmin
+    # (coarse pixels: the interpolant fails its check everywhere and every tile takes the exact path)
+    import os
+    for res_arcmin, n_car in ((0.5, 43200), (20.0, 1080)):
+        fshape, fwcs = pj.fullsky_geometry(2 * math.pi / n_car)
+        if n_car > 2000:           # a declination strip of the full-sky map is enough for the oracle's patience
+            fshape, fwcs = pj.slice_geometry(fshape, fwcs, None, (10801 - 700, 10801 + 700))
+        patch_wcs = pj.Gnomonic((res_arcmin / 60, res_arcmin / 60), (300.5, 200.5), (179.9, 0.3))
+        patch_shape = (600, 400)
+        src = smooth(fshape, 1)
+        m = pj.Enmap(to_dev(src[0], dev), fwcs)
+        tiled = pj.reproject(m, patch_shape, patch_wcs).data.cpu().numpy()
+        os.environ["PXL_GENERIC_EXACT"] = "1"
+        try:
+            exact = pj.reproject(m, patch_shape, patch_wcs).data.cpu().numpy()
+        finally:
+            del os.environ["PXL_GENERIC_EXACT"]
+        exp = O.reproject_generic(fwcs, 0, (fshape[0], fshape[1], 1), src, patch_wcs, 1, patch_shape)[0]
+        assert np.abs(exact - exp).max() < 1e-9 and np.abs(tiled - exp).max() < 1e-9, (res_arcmin, np.abs(tiled - exp).max())
+        assert np.abs(tiled - exact).max() < 1e-10, (res_arcmin, np.abs(tiled - exact).max())
+        assert np.abs(exp).max() > 0.1
     # consistency with the separable kernel when both maps are CAR
     fs = pj.fullsky_geometry(2 * math.pi / 200)
     fs2 = pj.fullsky_geometry(2 * math.pi / 300)
@@ -728,6 +751,13 @@ def test_unwind_inplace_and_overlap(pj, O, dev):
     big = torch.zeros((n + 8, 2), dtype=torch.float64, device=dev)
     with pytest.raises(RuntimeError):
         pj.pix2sky_(g, big[:n], big[8:], safe=True)
+    # the same refusal for small batches (the single-block form, n <= 8192), and exact aliasing still works there
+    for ns in (2, 100, 4096, 8192):
+        with pytest.raises(RuntimeError):
+            pj.pix2sky_(g, big[:ns], big[1:ns + 1], safe=True)
+        small = to_dev(walk[:ns], dev)
+        pj.pix2sky_(g, small, small, safe=True)
+        assert bits_equal(small.cpu().numpy(), O.pix2sky(g[1], walk[:ns], O.WRAP_UNWIND))
 
 
 def test_sample_row_pair_layout(pj, O, dev):

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""N2 at scale: a full-sky 0.5-arcmin CAR map (43200 x 21601 Float64, 7.5 GB) reprojected onto a mosaic of Gnomonic
+patches (4096 x 4096 at 0.5 arcmin each, 16 of them: 2.1 GB of output, far beyond the 256 MB Infinity Cache), with the
+tiled kernel (coordinates interpolated per tile) and with the per-pixel one (PXL_GENERIC_EXACT=1).  One JSON line per
+variant with a roofline block: algorithmic bytes = 8 B written + 8 B read per output pixel (each source pixel under a
+patch is read once; the patches have the source's resolution)."""
+import json, math, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import pixell_jl_amd as pj
+
+dev = torch.device("cuda:0")
+shape, wcs = pj.fullsky_geometry(2 * math.pi / 43200)
+m = pj.Enmap(torch.empty((shape[1], shape[0]), dtype=torch.float64, device=dev), wcs)
+pj.fill_random_(m.data, 1234)
+N = int(os.environ.get("PXL_PATCH", "4096"))
+res = 0.5 / 60
+patches = [pj.Gnomonic((res, res), (N / 2 + 0.5, N / 2 + 0.5), (ra, dec)) for dec in (-25.0, 25.0) for ra in range(0, 360, 45)]
+npix = len(patches) * N * N
+
+
+def run():
+    return [pj.reproject(m, (N, N), w) for w in patches]
+
+
+def timed(reps=3):
+    run(); torch.cuda.synchronize(); ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); outs = run(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+    return sorted(ts)[len(ts) // 2], outs
+
+
+rows = {}
+for name, env in (("tiled", None), ("per_pixel", "1")):
+    if env:
+        os.environ["PXL_GENERIC_EXACT"] = env
+    ms, outs = timed()
+    os.environ.pop("PXL_GENERIC_EXACT", None)
+    rows[name] = outs
+    import ctypes as C
+    ex, tot = C.c_int64(), C.c_int64()
+    pj._lib.check(pj.load_library().pxl_reproject_generic_last_tiles(C.byref(ex), C.byref(tot), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    alg = 16.0 * npix
+    print(json.dumps({"variant": name, "kernel": "k_reproject_generic_tiled" if name == "tiled" else "k_reproject_generic",
+                      "patches": len(patches), "patch": [N, N], "last_patch_exact_tiles": [ex.value, tot.value] if name == "tiled" else None, "ms": round(ms, 3), "Gpix/s": round(npix / ms / 1e6, 2),
+                      "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+                                   "frac": round(alg / ms / 1e6 / 8000, 4), "algorithmic_bytes": alg}}), flush=True)
+worst = max(float((a.data - b.data).abs().max()) for a, b in zip(rows["tiled"], rows["per_pixel"]))
+print(json.dumps({"max_abs_diff_tiled_vs_per_pixel": worst, "note": "N(0,1) white-noise map: a sampling-position error of e pixel moves a value by ~2e"}))
