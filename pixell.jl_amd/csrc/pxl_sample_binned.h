@@ -22,7 +22,7 @@
 // run, which changes where a record sits, never its value.
 //
 // What was measured (1e9 points, 43200 x 21601 Float64 map, profiles/r02_cfg5_binned_*.txt): the TLB
-// and DRAM problems do go away (UTCL1 misses 3.0e9 -> 1.6e4 in the gather, L2 hit rate 13 % -> 80 %), but every
+// and DRAM problems do go away (UTCL1 misses 3.0e9 -> 1.6e4 in the gather, L2 hit rate 13 % -> 90 %), but every
 // per-point DIVERGENT access costs about the same whatever it hits: a CU's L1 keeps only so many misses in flight, so
 // 64 lanes x 64 different lines run at 110-150 G lane-accesses/s chip-wide out of L2 (70 G/s for 16-byte stores).  The
 // binned pipeline pays six of those per point (1 record store, 4 taps, 1 value fetch) against the direct kernel's four:
