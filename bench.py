@@ -122,7 +122,7 @@ def cpu_baseline_reproject(shape_in, wcs_in, shape_out, wcs_out, budget_s=12.0):
                       "columns x %d components of the same workload" % (rowsN, rows1, nxo, nc)}
 
 
-def place_buffers(sh, candidates, dev, keep="first"):
+def place_buffers(sh, candidates, dev, keep="first", arena=True):
     """Allocate and fill the resident maps.  Where the driver puts a 20 GB buffer physically moves this
     HBM-bound kernel by up to 10 % (profiles/README.md: same virtual addresses, re-allocated, 7.35-8.13 ms).
     The headline number comes from the FIRST allocation (what a job gets without steering anything).  With
@@ -134,9 +134,14 @@ def place_buffers(sh, candidates, dev, keep="first"):
     best = None
     tried = []
     ballast = []
+    holds = []
     for k in range(max(1, candidates)):
-        src = sh.alloc_src()
-        dst = sh.alloc_dst()
+        if arena:       # one allocation, destination above the source (sharding.alloc_pair: a fixed policy, nothing probed)
+            src, dst, hold = sh.alloc_pair()
+            holds.append(hold)
+        else:
+            src = sh.alloc_src()
+            dst = sh.alloc_dst()
         fill_strip(sh, src, 1234)
         sh.plan.build_tables()
         n = sh.dst_window[1]
@@ -153,6 +158,7 @@ def place_buffers(sh, candidates, dev, keep="first"):
         if best is None or (keep == "best" and t < best[2]):
             best = (src, dst, t)
         del src, dst
+        holds.clear()
         if k + 1 < candidates:
             # return the losing blocks to the driver and perturb the heap so the next try lands elsewhere
             ballast.append(torch.empty(int(rng.uniform(0.3, 3.0) * 2**30), dtype=torch.uint8, device=dev))
@@ -161,7 +167,8 @@ def place_buffers(sh, candidates, dev, keep="first"):
             torch.cuda.empty_cache()
     del ballast
     torch.cuda.empty_cache()
-    return best[0], best[1], {"candidates_ms": tried, "chosen_ms": round(best[2], 4), "chosen": keep,
+    return best[0], best[1], {"allocation": "one arena, dst above src" if arena else "two allocations", "candidates_ms": tried,
+                              "chosen_ms": round(best[2], 4), "chosen": keep,
                               "first_ms": tried[0], "median_ms": sorted(tried)[len(tried) // 2], "best_ms": min(tried)}
 
 
@@ -182,9 +189,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=os.environ.get("PXL_BENCH_WORKLOAD", "cfg4"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustain-seconds", type=float, default=float(os.environ.get("PXL_BENCH_SUSTAIN_S", "5")),
+                    help="after the K timed steps (N = 1): keep issuing steps back to back for this long and report their "
+                         "mean as `sustained` (a thermally settled number, and GPU activity an outside sampler can see); 0 = off")
     ap.add_argument("--placements", type=int, default=int(os.environ.get("PXL_BENCH_PLACEMENTS", "1")),
                     help="buffer placements probed at setup (default 1: just the first allocation, which is what the "
                          "headline always reports unless --keep-placement best)")
+    ap.add_argument("--two-allocations", action="store_true",
+                    help="allocate the source and destination maps separately (default: carved out of one allocation, destination "
+                         "above the source -- a fixed policy; DESIGN 6)")
     ap.add_argument("--keep-placement", default="first", choices=["first", "best"],
                     help="which probed placement the timed steps run on (first = unselected headline)")
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the output of the timed run is always "
@@ -274,7 +287,7 @@ def bench_reproject(args, rank, world, dev):
     nx, ny, nc = shape_in
     nxo, nyo = shape_out
     sh = pj.DecStripReprojector(shape_in, wcs_in, shape_out, wcs_out, rank, world, dev)
-    src, dst, placement = place_buffers(sh, args.placements, dev, args.keep_placement)
+    src, dst, placement = place_buffers(sh, args.placements, dev, args.keep_placement, arena=not args.two_allocations)
     torch.cuda.synchronize(dev)
     # ---- choose the halo transport (N > 1).  Candidates in order: "native" = the library's own sharded step (RCCL
     # send/recv issued from C straight out of / into the resident buffer), "torch" = torch.distributed
@@ -418,6 +431,19 @@ def bench_reproject(args, rank, world, dev):
                      "kernel_ms_avg": round(k_avg_ms, 4), "kernel_ms_min": round(kms[0], 4),
                      "kernel_ms_median": round(kms[len(kms) // 2], 4)},
     }
+    if world == 1 and args.sustain_seconds > 0:
+        # NOT the headline: the K timed steps above are.  A few seconds of the same step, back to back.
+        nsus = max(args.steps, int(args.sustain_seconds / (dt / args.steps)))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(nsus):
+            one_step()
+        b.record()
+        torch.cuda.synchronize(dev)
+        sus_ms = a.elapsed_time(b) / nsus
+        result["sustained"] = {"steps": nsus, "seconds": round(a.elapsed_time(b) / 1e3, 2), "ms_per_step": round(sus_ms, 4),
+                               "frac": round(alg_bytes / (sus_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "note": "step = table build + reprojection, HIP events around the whole run; not the headline"}
     if world == 1 and args.placements > 1:
         # where the timed placement sits among the probed ones (probe medians of 4 launches each)
         f = lambda ms: round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)

@@ -116,6 +116,7 @@ struct pxl_reproject_plan {
     int dxpos;
     int flags;
     int ns, pf;
+    int64_t xchunk;
     double* zero_page;
     bool staged_ok;
     bool vec_load;
@@ -593,6 +594,7 @@ int pxl_reproject_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[
     if (pl->ns < 4) pl->ns = 4;
     while (pl->ns & (pl->ns - 1)) pl->ns &= pl->ns - 1;       // power of two
     if (pl->ns > 64) pl->ns = 64;
+    pl->xchunk = env_int("PXL_REPROJECT_XCHUNK", 0);
     pl->pf = env_int("PXL_REPROJECT_PF", 3);
     if (pl->pf < 0) pl->pf = 0;
     const int max_seg = PXL_MAXCH * 128;
@@ -714,7 +716,9 @@ static int reproject_rows_impl(pxl_reproject_plan* pl, const void* src, void* ds
     p.nty = (int32_t)((nr + rh - 1) / rh);
     p.ntiles = (int64_t)p.ntx * p.nty * pl->nc;
     p.tiles_per_xcd = (p.ntiles + 7) / 8;
-    int64_t nblocks = p.tiles_per_xcd * 8;
+    // PXL_REPROJECT_XCHUNK: tiles an XCD takes in one piece (0 = one contiguous eighth of the launch per XCD)
+    p.xchunk = pl->xchunk > 0 && pl->xchunk < p.tiles_per_xcd ? pl->xchunk : p.tiles_per_xcd;
+    int64_t nblocks = (p.ntiles + 8 * p.xchunk - 1) / (8 * p.xchunk) * (8 * p.xchunk);
     if (nblocks > 0x7fffffffLL) return fail(PXL_EINVAL, "execute: too many tiles (%lld)", (long long)nblocks);
     dim3 grid((unsigned)nblocks), block(64);
     if (use_dma) {

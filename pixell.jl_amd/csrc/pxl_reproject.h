@@ -39,11 +39,23 @@ struct ReprojParams {
     int32_t dypos;         // source row increases with output row
     int32_t ntx, nty;      // tiles along RA / DEC
     int64_t ntiles, tiles_per_xcd;
+    int64_t xchunk;        // tiles an XCD takes in one piece (xcd_tile below); tiles_per_xcd = one contiguous eighth each
     int32_t flags;         // tuning/diagnostics: 1 = skip source loads, 2 = skip stores, 4 = no XCD remap
     // LDS-DMA kernel only
     int32_t ns, pf;        // ring slots (power of two), prefetch distance in output rows
     const double* zero_page;   // 16 bytes of zeros in device memory
 };
+
+// Block -> tile with XCD affinity.  Blocks b and b + 8 share an XCD (workgroups are dealt round-robin over the 8 XCDs),
+// so XCD v = b % 8 is given the tiles of chunks v, v + 8, v + 16, ... of `chunk` consecutive tiles each: inside a
+// chunk neighbouring tiles (shared 128-byte lines, shared halo rows) meet in one L2.  chunk = ntiles / 8 is one
+// contiguous eighth of the map per XCD (round 1); smaller chunks keep the eight write fronts a chunk apart instead of
+// an eighth of the map apart.  The grid must cover ceil(ntiles / (8 chunk)) * 8 chunk blocks.
+__device__ inline int64_t xcd_tile(int64_t b, int64_t chunk) {
+    const int64_t v = b & 7, j = b >> 3;
+    const int64_t c = j / chunk, w = j - c * chunk;
+    return (c * 8 + v) * chunk + w;
+}
 
 // ---- generic direct-gather kernel: one lane per output pixel pair, 4 taps from global memory each.
 //      Used when a tile's source footprint does not fit the LDS ring (large down-scaling) and as the
@@ -138,7 +150,7 @@ __global__ __launch_bounds__(64) void k_reproject_staged(ReprojParams p) {
     // contiguous run of tiles so RA-neighbouring tiles (which share 128-B lines at their edges and the
     // same source rows) hit the same L2.  Placement only affects speed, never correctness.
     const int64_t b = blockIdx.x;
-    const int64_t t = (p.flags & 4) ? b : (b & 7) * p.tiles_per_xcd + (b >> 3);
+    const int64_t t = (p.flags & 4) ? b : xcd_tile(b, p.xchunk);
     if (t >= p.ntiles) return;
     const int tx = (int)(t % p.ntx);
     const int64_t trest = t / p.ntx;
