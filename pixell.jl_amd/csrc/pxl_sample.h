@@ -67,9 +67,9 @@ __global__ __launch_bounds__(256) void k_reproject_generic(GenericParams p) {
 
 // ---- the same operator with the coordinate map interpolated per output tile (what python-pixell does for non-
 // separable reprojections, and the only way off the transcendental roof: ~10 FP64 libm calls per pixel above).
-// Tile = 64 x 16 output pixels.  The exact (x, y) of the reference's
-// evaluators is computed on a 6 x 5 lattice of the tile (36 evaluations per 1024 pixels with the check points) and
-// every pixel takes the tensor-product Lagrange interpolant of degree 5 x 4 (error ~ h^6 f^(6) / 6!: 1e-14 pixel at
+// Tile = 64 x 32 output pixels.  The exact (x, y) of the reference's
+// evaluators is computed on a 6 x 6 lattice of the tile (42 evaluations per 2048 pixels with the check points) and
+// every pixel takes the tensor-product Lagrange interpolant of degree 5 x 5 (error ~ h^6 f^(6) / 6!: 1e-14 pixel at
 // 0.5 arcmin, below the rounding noise of the exact evaluation).  The interpolant is CHECKED per tile against exact evaluations at six off-lattice points: if either
 // coordinate is off by more than PXL_TILED_TOL pixel anywhere, or a lattice point is non-finite or behind the
 // tangent plane (the rewind jump of a periodic source and the Gnomonic horizon land here), the whole tile takes the
@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256) void k_reproject_generic(GenericParams p) {
 // a few ulp through atan2 / asin / division by the pixel size), so a tighter check fails on noise, not on the interpolant
 #define PXL_TILED_TOL 1e-10
 #define PXL_TNX 6
-#define PXL_TNY 5
+#define PXL_TNY 6
+#define PXL_TH 32          // tile height (output rows); width is one wave = 64 columns
 // Lagrange basis on the N equispaced nodes 0, h, ..., (N-1) h.  The denominators prod_{c != a} (a - c) h are
 // constants (+-120, 24, 12 x h^5 for N = 6; 24, 6, 4 x h^4 for N = 5): no division in the kernel.
 template <int N>
@@ -105,11 +106,11 @@ __device__ inline void lagrange_weights(double u, double h, double* w) {
 // Two launches.  k_generic_lattice: every tile's 30 lattice points + 6 check points, all tiles in parallel (one wave
 // per tile; the ~10 libm calls per point are the expensive part and no pixel waits behind them); per tile it leaves the
 // lattice coordinates and a flag (1 = the interpolant failed its check or a point is non-finite / not visible).
-// k_reproject_generic_tiled: one block per tile, 4 pixels per thread, no LDS and no barrier: the tile's lattice is
+// k_reproject_generic_tiled: one block per tile, 8 pixels per thread, no LDS and no barrier: the tile's lattice is
 // wave-uniform data.
 // The pixels of a tile sit at integer positions 0..63 x 0..15 of the lattice's coordinate system, the same in every
 // tile: their Lagrange weights are compile-time tables.
-struct TileWeights { double wx[64][PXL_TNX]; double wy[16][PXL_TNY]; };
+struct TileWeights { double wx[64][PXL_TNX]; double wy[PXL_TH][PXL_TNY]; };
 constexpr double lag_w(int n, double h, double u, int a) {
     double num = 1.0, den = 1.0;
     for (int c = 0; c < n; ++c)
@@ -120,8 +121,8 @@ constexpr TileWeights make_tile_weights() {
     TileWeights t{};
     for (int u = 0; u < 64; ++u)
         for (int a = 0; a < PXL_TNX; ++a) t.wx[u][a] = lag_w(PXL_TNX, 63.0 / (PXL_TNX - 1), (double)u, a);
-    for (int v = 0; v < 16; ++v)
-        for (int b = 0; b < PXL_TNY; ++b) t.wy[v][b] = lag_w(PXL_TNY, 15.0 / (PXL_TNY - 1), (double)v, b);
+    for (int v = 0; v < PXL_TH; ++v)
+        for (int b = 0; b < PXL_TNY; ++b) t.wy[v][b] = lag_w(PXL_TNY, (PXL_TH - 1.0) / (PXL_TNY - 1), (double)v, b);
     return t;
 }
 __constant__ TileWeights c_tile_weights = make_tile_weights();
@@ -133,8 +134,8 @@ __global__ __launch_bounds__(256) void k_generic_lattice(GenericParams p, int64_
     const int w = threadIdx.x >> 6, k = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * 4 + w;
     const bool live = tile < ntiles;
-    const int64_t ti0 = live ? (tile % ntx) * 64 : 0, tj0 = live ? (tile / ntx) * 16 : 0;
-    const double hx = 63.0 / (PXL_TNX - 1), hy = 15.0 / (PXL_TNY - 1);
+    const int64_t ti0 = live ? (tile % ntx) * 64 : 0, tj0 = live ? (tile / ntx) * PXL_TH : 0;
+    const double hx = 63.0 / (PXL_TNX - 1), hy = (PXL_TH - 1.0) / (PXL_TNY - 1);
     if (k == 0) bad[w] = 0;
     __syncthreads();
     double ex = 0.0, ey = 0.0, cu = 0.0, cv = 0.0;
@@ -146,9 +147,10 @@ __global__ __launch_bounds__(256) void k_generic_lattice(GenericParams p, int64_
         lx[w][k] = ex; ly[w][k] = ey;
         lat[tile * (PXL_TNX * PXL_TNY) + k] = make_double2(ex, ey);
         if (!vis || !isfinite(ex) || !isfinite(ey)) bad[w] = 1;
-    } else if (live && k >= 32 && k < 38) {
-        const double us[6] = {6.3, 31.5, 56.7, 18.9, 44.1, 59.85}, vs[6] = {1.9, 7.5, 13.1, 11.2, 3.7, 14.1};
-        cu = us[k - 32]; cv = vs[k - 32];
+    } else if (live && k >= 40 && k < 46) {
+        const double us[6] = {6.3, 31.5, 56.7, 18.9, 44.1, 59.85};
+        const double vs[6] = {0.12 * PXL_TH, 0.47 * PXL_TH, 0.82 * PXL_TH, 0.70 * PXL_TH, 0.23 * PXL_TH, 0.94 * (PXL_TH - 1)};
+        cu = us[k - 40]; cv = vs[k - 40];
         bool vis;
         generic_coords(p, (double)(ti0 + 1) + cu, (double)(tj0 + 1) + cv, &ex, &ey, &vis);
         is_check = true;
@@ -179,9 +181,9 @@ __global__ __launch_bounds__(256) void k_generic_lattice(GenericParams p, int64_
 __global__ __launch_bounds__(256) void k_reproject_generic_exact_tiles(GenericParams p, const int32_t* __restrict__ flag) {
     const int64_t tile = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
     if (!flag[tile]) return;
-    const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63), jr0 = (int64_t)blockIdx.y * 16 + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63), jr0 = (int64_t)blockIdx.y * PXL_TH + (threadIdx.x >> 6);
     if (i >= p.nxo) return;
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < PXL_TH / 4; ++q) {
         const int64_t jr = jr0 + 4 * q;
         if (jr < p.nyo) {
             double x, y; bool visible;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256) void k_reproject_generic_exact_tiles(GenericPa
 __global__ __launch_bounds__(256) void k_reproject_generic_tiled(GenericParams p, const double2* __restrict__ lat,
                                                                  const int32_t* __restrict__ flag) {
     const int64_t tile = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-    const int64_t ti0 = (int64_t)blockIdx.x * 64, tj0 = (int64_t)blockIdx.y * 16;      // 0-based tile origin
+    const int64_t ti0 = (int64_t)blockIdx.x * 64, tj0 = (int64_t)blockIdx.y * PXL_TH;   // 0-based tile origin
     const int tid = threadIdx.x;
     const int cx = tid & 63, ry = tid >> 6;
     const int64_t i = ti0 + cx;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256) void k_reproject_generic_tiled(GenericParams p
         colx[b] = sx; coly[b] = sy;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < PXL_TH / 4; ++q) {
         const int r = ry + 4 * q;
         const int64_t jr = tj0 + r;
         if (jr < p.nyo) {
