@@ -1148,6 +1148,7 @@ struct pxl_sample_plan {
                             // 1 = records in registers, source strips streamed through LDS by LDS-DMA (k_sample_tile_regs)
     int rt;                 // records per thread of the LDS form
     uint32_t* wstart; uint32_t* item; int64_t items_max;
+    int64_t bound_n;        // points of the batch whose records / slots the workspace holds (-1: none)
     bool dma_ok;            // geometry allows 16-byte LDS-DMA staging (nx and tile width multiples of 16 B)
     void* zero_page;
     int sh, ns, pitch;      // strip height (source rows), strips per tile, LDS row pitch in elements
@@ -1177,6 +1178,7 @@ int pxl_sample_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[3],
     pl->w = *wcs_in;
     pl->nx = shape_in[0]; pl->ny = shape_in[1]; pl->nc = shape_in[2];
     pl->row0 = src_row0; pl->nrows = src_nrows; pl->nmax = nmax; pl->dtype = elem_bytes;
+    pl->bound_n = -1;
     pl->periodic = fabs((double)pl->nx * fabs(wcs_in->cdelt[0] * wcs_in->unit) - PXL_TWOPI_D) < 1e-8;
     hipError_t e = hipGetDevice(&pl->device);
     if (e != hipSuccess) { delete pl; return fail(PXL_ENODEV, "hipGetDevice: %s", hipGetErrorString(e)); }
@@ -1269,14 +1271,13 @@ int pxl_sample_plan_destroy(pxl_sample_plan* pl) {
 }
 
 }  // extern "C"
-template <typename T>
-static int sample_plan_execute_t(pxl_sample_plan* pl, const T* src, int64_t n, const double* sky, T* out, void* stream) {
-    if (!pl) return fail(PXL_EINVAL, "sample_plan_execute: null plan");
-    if ((int)sizeof(T) != pl->dtype) return fail(PXL_EINVAL, "sample_plan_execute: plan was created for %d-byte elements", pl->dtype);
-    if (n < 0 || n > pl->nmax) return fail(PXL_EINVAL, "sample_plan_execute: n outside [0, nmax]");
-    if (n > 0 && (!sky || !out || (!src && pl->nrows > 0))) return fail(PXL_EINVAL, "sample_plan_execute: null buffer");
-    if (((uintptr_t)sky & 15) != 0) return fail(PXL_EINVAL, "sample_plan_execute: 2xN buffer must be 16-byte aligned");
-    if (n == 0) return PXL_OK;
+static int sample_plan_bind(pxl_sample_plan* pl, int64_t n, const double* sky, void* stream) {
+    if (!pl) return fail(PXL_EINVAL, "sample_plan_bind: null plan");
+    if (n < 0 || n > pl->nmax) return fail(PXL_EINVAL, "sample_plan_bind: n outside [0, nmax]");
+    if (n > 0 && !sky) return fail(PXL_EINVAL, "sample_plan_bind: null batch");
+    if (((uintptr_t)sky & 15) != 0) return fail(PXL_EINVAL, "sample_plan_bind: 2xN buffer must be 16-byte aligned");
+    pl->bound_n = -1;
+    if (n == 0) { pl->bound_n = 0; return PXL_OK; }
     hipStream_t st = (hipStream_t)stream;
     const Sky2Pix s = sky2pix_setup(pl->w, pl->nx, pl->ny, 1, PXL_FORM_RECIP);
     const BinGrid g = pl->g;
@@ -1306,7 +1307,24 @@ static int sample_plan_execute_t(pxl_sample_plan* pl, const T* src, int64_t n, c
     else                   hipLaunchKernelGGL((k_bin_scatter<32>), cgrid, cblock, (size_t)B * 4, st, s, g, n, (const double2*)sky,
                                               (const uint32_t*)pl->off, pl->rec, pl->slot);
     rc = check_launch("k_bin_scatter");
-    if (rc || stop < 4) return rc;
+    if (rc == PXL_OK) pl->bound_n = n;
+    return rc;
+}
+
+template <typename T>
+static int sample_plan_sample_bound_t(pxl_sample_plan* pl, const T* src, T* out, void* stream) {
+    if (!pl) return fail(PXL_EINVAL, "sample_plan_sample_bound: null plan");
+    if ((int)sizeof(T) != pl->dtype) return fail(PXL_EINVAL, "sample_plan_sample_bound: plan was created for %d-byte elements", pl->dtype);
+    if (pl->bound_n < 0) return fail(PXL_EINVAL, "sample_plan_sample_bound: no batch is bound (pxl_sample_plan_bind first)");
+    const int64_t n = pl->bound_n;
+    if (n == 0) return PXL_OK;
+    if (!out || (!src && pl->nrows > 0)) return fail(PXL_EINVAL, "sample_plan_sample_bound: null buffer");
+    hipStream_t st = (hipStream_t)stream;
+    const BinGrid g = pl->g;
+    const int B = g.B;
+    const int stop = env_int("PXL_SAMPLE_STOP", 5);
+    int rc = PXL_OK;
+    if (stop < 4) return rc;
     const int64_t per_block = 256LL * PXL_BIN_SUNR * pl->trips;
     const int64_t nblk8 = ((n + per_block - 1) / per_block + 7) / 8;
     const size_t lds = (size_t)(pl->sh + 1) * pl->pitch * sizeof(T);
@@ -1346,6 +1364,16 @@ static int sample_plan_execute_t(pxl_sample_plan* pl, const T* src, int64_t n, c
     return check_launch("k_sample_binned");
 }
 
+
+template <typename T>
+static int sample_plan_execute_t(pxl_sample_plan* pl, const T* src, int64_t n, const double* sky, T* out, void* stream) {
+    if (!pl) return fail(PXL_EINVAL, "sample_plan_execute: null plan");
+    if ((int)sizeof(T) != pl->dtype) return fail(PXL_EINVAL, "sample_plan_execute: plan was created for %d-byte elements", pl->dtype);
+    if (n > 0 && (!out || (!src && pl->nrows > 0))) return fail(PXL_EINVAL, "sample_plan_execute: null buffer");
+    int rc = sample_plan_bind(pl, n, sky, stream);
+    if (rc || pl->bound_n < 0) return rc;          // bound_n < 0: a diagnostic stop before the scatter
+    return sample_plan_sample_bound_t<T>(pl, src, out, stream);
+}
 extern "C" {
 int pxl_sample_plan_execute_f64(pxl_sample_plan* plan, const double* src, int64_t n, const double* sky2xN, double* out, void* stream) {
     return sample_plan_execute_t<double>(plan, src, n, sky2xN, out, stream);
@@ -1353,6 +1381,18 @@ int pxl_sample_plan_execute_f64(pxl_sample_plan* plan, const double* src, int64_
 
 int pxl_sample_plan_execute_f32(pxl_sample_plan* plan, const float* src, int64_t n, const double* sky2xN, float* out, void* stream) {
     return sample_plan_execute_t<float>(plan, src, n, sky2xN, out, stream);
+}
+
+int pxl_sample_plan_bind(pxl_sample_plan* plan, int64_t n, const double* sky2xN, void* stream) {
+    return sample_plan_bind(plan, n, sky2xN, stream);
+}
+
+int pxl_sample_plan_sample_bound_f64(pxl_sample_plan* plan, const double* src, double* out, void* stream) {
+    return sample_plan_sample_bound_t<double>(plan, src, out, stream);
+}
+
+int pxl_sample_plan_sample_bound_f32(pxl_sample_plan* plan, const float* src, float* out, void* stream) {
+    return sample_plan_sample_bound_t<float>(plan, src, out, stream);
 }
 
 int pxl_fits_decode_f64(const void* raw_be, double* dst, int64_t n, int bitpix, void* stream) {

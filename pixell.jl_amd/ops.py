@@ -449,6 +449,7 @@ class SampleBinned:
         self.src_rows = (0, self.shape[1]) if src_rows is None else (int(src_rows[0]), int(src_rows[1]))
         self.dtype, self.device, self.nmax = data.dtype, data.device, int(nmax)
         self.data = data
+        self._bound = (0, data.device)
         self._h = _lib.C.c_void_p()
         lib = _lib.load()
         with torch.cuda.device(data.device):
@@ -481,6 +482,32 @@ class SampleBinned:
         fn = lib.pxl_sample_plan_execute_f32 if self.dtype == torch.float32 else lib.pxl_sample_plan_execute_f64
         with torch.cuda.device(sky.device):
             _lib.check(fn(self._h, _ptr(data), sky.shape[0], _ptr(sky), _ptr(out), _stream(sky)))
+        self._bound = (sky.shape[0], sky.device)          # execute = bind + sample_bound: the batch stays bound
+        return out
+
+    def bind(self, skycoords: torch.Tensor):
+        """Count and scatter a 2xN batch into the plan's tiles once; sample_bound() then samples it from any map of the
+        plan's geometry (the same pointing against several maps / iterations)."""
+        sky = _dev_f64(skycoords, "skycoords")
+        self._bound = (sky.shape[0], sky.device)
+        with torch.cuda.device(sky.device):
+            _lib.check(_lib.load().pxl_sample_plan_bind(self._h, sky.shape[0], _ptr(sky), _stream(sky)))
+        return self
+
+    def sample_bound(self, data: torch.Tensor = None, out: torch.Tensor = None) -> torch.Tensor:
+        """(nc, N) samples of `data` (default: the plan's map) at the bound batch."""
+        n, dev = self._bound
+        data = self.data if data is None else _dev_map(data, "map data")
+        if data.dtype != self.dtype or data.numel() != self.nc * self.src_rows[1] * self.shape[0]:
+            raise ValueError("map data does not match the plan")
+        if out is None:
+            out = torch.empty((self.nc, n), dtype=self.dtype, device=dev)
+        elif out.dtype != self.dtype or out.numel() != self.nc * n or not out.is_contiguous() or out.device != dev:
+            raise ValueError("out must be a contiguous (nc, N) tensor of the map's dtype on the batch's device")
+        lib = _lib.load()
+        fn = lib.pxl_sample_plan_sample_bound_f32 if self.dtype == torch.float32 else lib.pxl_sample_plan_sample_bound_f64
+        with torch.cuda.device(dev):
+            _lib.check(fn(self._h, _ptr(data), _ptr(out), _stream(out)))
         return out
 
     def close(self):

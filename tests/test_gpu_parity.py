@@ -851,6 +851,20 @@ def test_sample_binned_plan(pj, O, dev, monkeypatch):
                     assert _same_bits_or_nan(got, expect), (name, pt, nc, r0, nr)
                     assert _same_bits_or_nan(got2, expect[:, :pt * 1024 + 3]), (name, pt, nc, r0, nr)
                 assert np.array_equal(np.isnan(got), np.isnan(expect))
+    # bind once, sample the same batch from two different maps (execute == bind + sample_bound)
+    shape, wcs = pj.fullsky_geometry(2 * math.pi / 300)
+    nx, ny = shape
+    n = 50_000
+    sky = np.stack([2 * math.pi * rng.random(n) - math.pi, np.arcsin(2 * rng.random(n) - 1)], axis=1)
+    maps = [rng.normal(size=(2, ny, nx)) for _ in range(2)]
+    plan = pj.SampleBinned(pj.Enmap(to_dev(maps[0], dev), wcs), n)
+    with pytest.raises(RuntimeError):
+        plan.sample_bound()                                          # nothing bound yet
+    plan.bind(to_dev(sky, dev))
+    for src in maps:
+        got = plan.sample_bound(to_dev(src, dev)).cpu().numpy()
+        assert _same_bits_or_nan(got, O.sample_bilinear(wcs, (nx, ny, 2), src, sky))
+    plan.close()
     # empty batch, argument checks
     shape, wcs = pj.fullsky_geometry(1 * DEG)
     m = pj.Enmap(torch.zeros((shape[1], shape[0]), dtype=torch.float64, device=dev), wcs)

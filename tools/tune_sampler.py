@@ -40,12 +40,14 @@ for cfg in sys.argv[1:] or [""]:
         os.environ["PXL_SAMPLE_STOP"] = str(stop)
         cum.append(t(lambda: plan.sample(sky, out=out)))
     del os.environ["PXL_SAMPLE_STOP"]
+    plan.bind(sky)
+    bound_ms = t(lambda: plan.sample_bound(out=out))
     if ref is None:
         ref = pj.sample_bilinear(m, sky[:2_000_000])
     ok = bool(torch.equal(out[:, :2_000_000].view(torch.int64), ref.view(torch.int64)))
     st = [cum[0]] + [cum[i] - cum[i - 1] for i in range(1, 5)]
     print(json.dumps({"cfg": cfg, "tiles": plan.tiles, "total_ms": round(cum[4], 2), "Gpts/s": round(n / cum[4] / 1e6, 2),
                       "count": round(st[0], 2), "tables": round(st[1], 2), "scatter": round(st[2], 2), "gather": round(st[3], 2),
-                      "unpermute": round(st[4], 2), "bits_equal_direct_first_2e6": ok, "workspace_GB": round(plan.workspace_bytes / 1e9, 1)}), flush=True)
+                      "unpermute": round(st[4], 2), "sample_bound_ms": round(bound_ms, 2), "bits_equal_direct_first_2e6": ok, "workspace_GB": round(plan.workspace_bytes / 1e9, 1)}), flush=True)
     plan.close()
     torch.cuda.empty_cache()
