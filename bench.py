@@ -122,7 +122,7 @@ def cpu_baseline_reproject(shape_in, wcs_in, shape_out, wcs_out, budget_s=12.0):
                       "columns x %d components of the same workload" % (rowsN, rows1, nxo, nc)}
 
 
-def place_buffers(sh, candidates, dev, keep="first", arena=True):
+def place_buffers(sh, candidates, dev, keep="first", arena=False):
     """Allocate and fill the resident maps.  Where the driver puts a 20 GB buffer physically moves this
     HBM-bound kernel by up to 10 % (profiles/README.md: same virtual addresses, re-allocated, 7.35-8.13 ms).
     The headline number comes from the FIRST allocation (what a job gets without steering anything).  With
@@ -195,9 +195,10 @@ def main():
     ap.add_argument("--placements", type=int, default=int(os.environ.get("PXL_BENCH_PLACEMENTS", "1")),
                     help="buffer placements probed at setup (default 1: just the first allocation, which is what the "
                          "headline always reports unless --keep-placement best)")
-    ap.add_argument("--two-allocations", action="store_true",
-                    help="allocate the source and destination maps separately (default: carved out of one allocation, destination "
-                         "above the source -- a fixed policy; DESIGN 6)")
+    ap.add_argument("--arena", action="store_true",
+                    help="carve the source and destination maps out of ONE allocation, destination above the source (default: "
+                         "two separate allocations, what any caller gets; where the destination lands physically moves the "
+                         "kernel by up to 8 %% either way -- DESIGN 9 item 6)")
     ap.add_argument("--keep-placement", default="first", choices=["first", "best"],
                     help="which probed placement the timed steps run on (first = unselected headline)")
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the output of the timed run is always "
@@ -287,7 +288,7 @@ def bench_reproject(args, rank, world, dev):
     nx, ny, nc = shape_in
     nxo, nyo = shape_out
     sh = pj.DecStripReprojector(shape_in, wcs_in, shape_out, wcs_out, rank, world, dev)
-    src, dst, placement = place_buffers(sh, args.placements, dev, args.keep_placement, arena=not args.two_allocations)
+    src, dst, placement = place_buffers(sh, args.placements, dev, args.keep_placement, arena=args.arena)
     torch.cuda.synchronize(dev)
     # ---- choose the halo transport (N > 1).  Candidates in order: "native" = the library's own sharded step (RCCL
     # send/recv issued from C straight out of / into the resident buffer), "torch" = torch.distributed

@@ -195,9 +195,10 @@ class DecStripReprojector(DecStripLayout):
     def alloc_pair(self, dtype=torch.float64):
         """Source and destination buffers carved out of ONE device allocation, destination above the source on a 2 MiB
         boundary.  Where the write stream lands physically moves the reprojection by up to 8 % (stores alone: 3.2 vs 3.7
-        ms for 22 GB, same kernel; tools/native/exp_placement_vmm.cpp, profiles/r02_placement_arena.jsonl); two separate
-        allocations land anywhere (7.3-8.0 ms), this arrangement measured 7.2-7.35 ms in 9 of 10 processes.  A fixed
-        policy, nothing is probed.  Returns (src zero-filled, dst, arena) -- keep `arena` alive."""
+        ms for 22 GB, same kernel; tools/native/exp_placement_vmm.cpp, profiles/r02_placement_arena.jsonl).  For the
+        0.5-arcmin IQU map this arrangement measured 7.2-7.35 ms in 9 of 10 processes (two allocations: 7.3-8.0); for a
+        small source and a large destination it measured slower: an option, not a rule.
+        Returns (src zero-filled, dst, arena) -- keep `arena` alive."""
         ns = 1
         for d in self.src_tensor_shape():
             ns *= d
