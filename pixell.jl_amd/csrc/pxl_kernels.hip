@@ -1190,7 +1190,7 @@ int pxl_sample_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[3],
     if (th > pl->ny) th = pl->ny;
     pl->gather = env_int("PXL_SAMPLE_GATHER", 0) ? 1 : 0;
     pl->rt = env_int("PXL_SAMPLE_RT", 32) <= 16 ? 16 : 32;
-    int64_t tw, TX, TY, sh, pitch;
+    int64_t tw, TX, TY, sh, pitch, th_tried = 0;
     for (;;) {
         tw = tile_bytes / (th * elem_bytes);
         if (tw < 64) tw = 64;
@@ -1211,6 +1211,13 @@ int pxl_sample_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[3],
         if (th > 4096) th = 4096 / sh * sh > 0 ? 4096 / sh * sh : sh;       // 12 bits of row in the packed cell
         TY = (pl->ny + th - 1) / th;
         if (TX * TY <= 16384) break;
+        if (th >= pl->ny || th + sh > 4096 || th <= th_tried) {   // cannot grow the tiles any further (rows exhausted, 12-bit row
+                                                                   // field, or rounding to whole strips undid the growth)
+            delete pl;
+            return fail(PXL_EINVAL, "sample_plan_create: a %lld x %lld map needs more than 16384 tiles of at most %lld columns; "
+                                    "use pxl_sample_car_bilinear_* for it", (long long)shape_in[0], (long long)shape_in[1], (long long)tw);
+        }
+        th_tried = th;
         th += sh;
         if (th > pl->ny) th = pl->ny;
     }

@@ -876,6 +876,30 @@ def test_sample_binned_plan(pj, O, dev, monkeypatch):
         pj.SampleBinned(m, 0)
 
 
+@pytest.mark.timeout(120)
+def test_sample_plan_geometry_terminates_on_odd_shapes(pj, dev, monkeypatch):
+    """Plan creation picks a tile grid of at most 16384 tiles by growing the tiles; for very wide or very flat maps
+    that must end in a plan or in a clean error, never in a loop (both gathers, small and large tile / LDS budgets)."""
+    import itertools
+    made = refused = 0
+    for nx, ny, gather, tile_kb, lds_kb in itertools.product((1, 7, 1000, 400_000, 10_000_000, 1_000_000_000), (1, 3, 513, 1_000_000),
+                                                             (0, 1), (1, 1800), (1, 144)):
+        monkeypatch.setenv("PXL_SAMPLE_GATHER", str(gather))
+        monkeypatch.setenv("PXL_SAMPLE_TILE_KB", str(tile_kb))
+        monkeypatch.setenv("PXL_SAMPLE_LDS_KB", str(lds_kb))
+        wcs = pj.CarClenshawCurtis((-360.0 / nx, 180.0 / max(ny - 1, 1)), (nx / 2 + 0.5, (ny + 1) / 2), (0.0, 0.0))
+        m = pj.Enmap(torch.empty((1, 1), dtype=torch.float64, device=dev), wcs)      # the data is not touched by create
+        try:
+            plan = pj.SampleBinned(m, 1, src_rows=(0, 0), full_shape=(nx, ny, 1))
+            assert 1 <= plan.tiles[2] <= 16384 + 3
+            plan.close()
+            made += 1
+        except RuntimeError as e:
+            assert "tiles" in str(e)
+            refused += 1
+    assert made > 0 and refused > 0
+
+
 def _same_bits_or_nan(a, b):
     """Bit equality where both are numbers, NaN where either is (the payload of a NaN is not part of the contract)."""
     a, b = np.asarray(a), np.asarray(b)
