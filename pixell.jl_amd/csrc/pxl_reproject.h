@@ -40,7 +40,7 @@ struct ReprojParams {
     int32_t ntx, nty;      // tiles along RA / DEC
     int64_t ntiles, tiles_per_xcd;
     int64_t xchunk;        // tiles an XCD takes in one piece (xcd_tile below); tiles_per_xcd = one contiguous eighth each
-    int32_t flags;         // tuning/diagnostics: 1 = skip source loads, 2 = skip stores, 4 = no XCD remap
+    int32_t flags;         // tuning/diagnostics: 1 = skip source loads, 2 = skip stores, 4 = no XCD remap, 8 / 16 = tile order 1 / 2 of xcd_tile
     // LDS-DMA kernel only
     int32_t ns, pf;        // ring slots (power of two), prefetch distance in output rows
     const double* zero_page;   // 16 bytes of zeros in device memory
@@ -51,9 +51,15 @@ struct ReprojParams {
 // chunk neighbouring tiles (shared 128-byte lines, shared halo rows) meet in one L2.  chunk = ntiles / 8 is one
 // contiguous eighth of the map per XCD (round 1); smaller chunks keep the eight write fronts a chunk apart instead of
 // an eighth of the map apart.  The grid must cover ceil(ntiles / (8 chunk)) * 8 chunk blocks.
-__device__ inline int64_t xcd_tile(int64_t b, int64_t chunk) {
+// order: 0 = every XCD walks its piece upwards from its start (eight write fronts a piece apart, moving in lockstep);
+// 1 = odd XCDs walk downwards (the distances between fronts change all the time); 2 = XCD v starts v/8 of the way into
+// its piece and wraps around (fronts 9/8 of a piece apart).  Experiments on the write-placement effect.
+__device__ inline int64_t xcd_tile(int64_t b, int64_t chunk, int order = 0) {
     const int64_t v = b & 7, j = b >> 3;
-    const int64_t c = j / chunk, w = j - c * chunk;
+    const int64_t c = j / chunk;
+    int64_t w = j - c * chunk;
+    if (order == 1 && (v & 1)) w = chunk - 1 - w;
+    else if (order == 2) { w += v * (chunk / 8); if (w >= chunk) w -= chunk; }
     return (c * 8 + v) * chunk + w;
 }
 
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(64) void k_reproject_staged(ReprojParams p) {
     // contiguous run of tiles so RA-neighbouring tiles (which share 128-B lines at their edges and the
     // same source rows) hit the same L2.  Placement only affects speed, never correctness.
     const int64_t b = blockIdx.x;
-    const int64_t t = (p.flags & 4) ? b : xcd_tile(b, p.xchunk);
+    const int64_t t = (p.flags & 4) ? b : xcd_tile(b, p.xchunk, (p.flags & 8) ? 1 : ((p.flags & 16) ? 2 : 0));
     if (t >= p.ntiles) return;
     const int tx = (int)(t % p.ntx);
     const int64_t trest = t / p.ntx;

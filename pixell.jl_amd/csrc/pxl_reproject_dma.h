@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
     // XCD-aware decode: blocks b and b+8 share an XCD; give each XCD a contiguous run of tiles so that
     // RA-neighbouring tiles (shared 128-B lines at the edges, same source rows) meet in one L2.
     const int64_t b = blockIdx.x;
-    const int64_t t = (p.flags & 4) ? b : xcd_tile(b, p.xchunk);
+    const int64_t t = (p.flags & 4) ? b : xcd_tile(b, p.xchunk, (p.flags & 8) ? 1 : ((p.flags & 16) ? 2 : 0));
     if (t >= p.ntiles) return;
     // RA-fastest tile order (DEC-fastest, non-temporal loads and non-temporal stores were all measured:
     // each within 1 % of this; profiles/r01_tuning_sweeps.log)

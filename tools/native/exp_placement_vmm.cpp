@@ -23,6 +23,8 @@ static pxl_reproject_plan* g_plan;
 static pxl_reproject_plan *g_plan_full, *g_plan_loads, *g_plan_stores;
 static const int kChunks[] = {169, 676, 2704, 10816, 43264};      // tiles per XCD piece (169 tiles = one 16-row band of one plane)
 static pxl_reproject_plan* g_plan_chunk[5];
+static pxl_reproject_plan *g_plan_st_rr, *g_plan_st_chunk[5];
+static pxl_reproject_plan *g_plan_ord[2], *g_plan_st_ord[2];        // tile orders 1 (odd XCDs downwards) and 2 (staggered starts): full / stores only      // stores only: round-robin tiles (one front) / XCD pieces
 static hipStream_t g_st;
 
 static double time_kernel(double* src, double* dst) {
@@ -93,6 +95,23 @@ int main(int argc, char** argv) {
         CHECK_PXL(pxl_reproject_plan_create(&win, shape_in, 0, NY, &wout, shape_out, 0, NY, &g_plan_chunk[k]));
     }
     unsetenv("PXL_REPROJECT_XCHUNK");
+    setenv("PXL_REPROJECT_FLAGS", "68", 1);      // stores only + no XCD remap (tile = block index: one write front, all XCDs interleaved)
+    CHECK_PXL(pxl_reproject_plan_create(&win, shape_in, 0, NY, &wout, shape_out, 0, NY, &g_plan_st_rr));
+    setenv("PXL_REPROJECT_FLAGS", "64", 1);
+    for (int k = 0; k < 5; ++k) {
+        char v[32]; snprintf(v, sizeof v, "%d", kChunks[k]);
+        setenv("PXL_REPROJECT_XCHUNK", v, 1);
+        CHECK_PXL(pxl_reproject_plan_create(&win, shape_in, 0, NY, &wout, shape_out, 0, NY, &g_plan_st_chunk[k]));
+    }
+    unsetenv("PXL_REPROJECT_XCHUNK");
+    const char* ordflags[2][2] = {{"8", "72"}, {"16", "80"}};
+    for (int o = 0; o < 2; ++o) {
+        setenv("PXL_REPROJECT_FLAGS", ordflags[o][0], 1);
+        CHECK_PXL(pxl_reproject_plan_create(&win, shape_in, 0, NY, &wout, shape_out, 0, NY, &g_plan_ord[o]));
+        setenv("PXL_REPROJECT_FLAGS", ordflags[o][1], 1);
+        CHECK_PXL(pxl_reproject_plan_create(&win, shape_in, 0, NY, &wout, shape_out, 0, NY, &g_plan_st_ord[o]));
+    }
+    unsetenv("PXL_REPROJECT_FLAGS");
     g_plan = g_plan_full;
     const size_t bytes = (size_t)NX * NY * NC * 8;
     for (int t = 0; t < trials; ++t) {
@@ -118,6 +137,8 @@ int main(int argc, char** argv) {
             char* a;
             CHECK_HIP(hipMalloc(&a, 2 * pad));
             double* lo = (double*)a; double* hi = (double*)(a + pad);
+            printf("{\"how\": \"arena addresses\", \"lo_va_mod_32GiB_in_GiB\": %.3f, \"hi_va_mod_32GiB_in_GiB\": %.3f}\n",
+                   fmod((double)(uintptr_t)lo, 34359738368.0) / 1073741824.0, fmod((double)(uintptr_t)hi, 34359738368.0) / 1073741824.0);
             printf("{\"how\": \"arena, dst above src\", \"trial\": %d, \"kernel_ms\": %.4f}\n", t, time_kernel(lo, hi)); fflush(stdout);
             printf("{\"how\": \"arena, dst below src\", \"trial\": %d, \"kernel_ms\": %.4f}\n", t, time_kernel(hi, lo)); fflush(stdout);
             g_plan = g_plan_loads;
@@ -126,12 +147,45 @@ int main(int argc, char** argv) {
             g_plan = g_plan_stores;
             printf("{\"how\": \"arena, STORES ONLY to the high half\", \"trial\": %d, \"kernel_ms\": %.4f}\n", t, time_kernel(lo, hi));
             printf("{\"how\": \"arena, STORES ONLY to the low half\", \"trial\": %d, \"kernel_ms\": %.4f}\n", t, time_kernel(hi, lo));
+            for (int o = 0; o < 2; ++o) {
+                g_plan = g_plan_st_ord[o];
+                printf("{\"how\": \"arena, STORES ONLY, tile order %d\", \"trial\": %d, \"to_high_ms\": %.4f, \"to_low_ms\": %.4f}\n", o + 1, t, time_kernel(lo, hi), time_kernel(hi, lo));
+                g_plan = g_plan_ord[o];
+                printf("{\"how\": \"arena, full kernel, tile order %d\", \"trial\": %d, \"dst_above_ms\": %.4f, \"dst_below_ms\": %.4f}\n", o + 1, t, time_kernel(lo, hi), time_kernel(hi, lo));
+            }
+            g_plan = g_plan_st_rr;
+            printf("{\"how\": \"arena, STORES ONLY, one front (tile = block)\", \"trial\": %d, \"to_high_ms\": %.4f, \"to_low_ms\": %.4f}\n", t, time_kernel(lo, hi), time_kernel(hi, lo));
+            for (int k = 0; k < 5; ++k) {
+                g_plan = g_plan_st_chunk[k];
+                printf("{\"how\": \"arena, STORES ONLY, XCD pieces of %d tiles\", \"trial\": %d, \"to_high_ms\": %.4f, \"to_low_ms\": %.4f}\n", kChunks[k], t,
+                       time_kernel(lo, hi), time_kernel(hi, lo));
+            }
             for (int k = 0; k < 5; ++k) {
                 g_plan = g_plan_chunk[k];
                 printf("{\"how\": \"arena, XCD pieces of %d tiles\", \"trial\": %d, \"dst_above_ms\": %.4f, \"dst_below_ms\": %.4f}\n", kChunks[k], t,
                        time_kernel(lo, hi), time_kernel(hi, lo));
             }
             g_plan = g_plan_full; fflush(stdout);
+            CHECK_HIP(hipFree(a));
+        }
+        {   // where in a big allocation does the store rate change?  One 70 GB allocation, the destination at growing offsets
+            const size_t big = (size_t)70 << 30;
+            char* a;
+            CHECK_HIP(hipMalloc(&a, big));
+            g_plan = g_plan_stores;
+            const double offs_gib[] = {0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48};
+            const double G32 = 34359738368.0;
+            for (double og : offs_gib) {
+                const size_t off = (size_t)(og * 1024) << 20;
+                if (off + bytes > big) break;
+                const double va = (double)(uintptr_t)(a + off);
+                printf("{\"how\": \"70 GB allocation, STORES ONLY at offset\", \"trial\": %d, \"offset_GiB\": %.2f, \"dst_va_mod_32GiB_in_GiB\": %.3f, "
+                       "\"dst_end_mod_32GiB_in_GiB\": %.3f, \"kernel_ms\": %.4f}\n", t, og, fmod(va, G32) / 1073741824.0,
+                       fmod(va + (double)bytes, G32) / 1073741824.0,
+                       time_kernel((double*)(a + (off + bytes <= big / 2 ? big - bytes : 0)), (double*)(a + off)));
+                fflush(stdout);
+            }
+            g_plan = g_plan_full;
             CHECK_HIP(hipFree(a));
         }
         if (t == 0) {
