@@ -74,3 +74,45 @@ def test_native_host_makes_its_own_communicator(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "native_sharded ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
     assert "loaded by libpixell_hip" in r.stdout          # the library's own RCCL instance, not one found in the process
+
+
+def test_plan_execute_is_graph_capturable():
+    """the launch path of a reprojection plan allocates nothing and never synchronises, so a whole step
+    (table build + interior + boundary launches) can be captured into ONE HIP graph and replayed; the replay must
+    give the bits of the eager launches, also after the source changed."""
+    import math
+    import torch
+    import pixell_jl_amd as pj
+    dev = torch.device("cuda:0")
+    shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 1200, dims=(2,))
+    shape_out, wcs_out = pj.fullsky_geometry(2 * math.pi / 2400)
+    plan = pj.ReprojectPlan(shape_in, wcs_in, shape_out, wcs_out, device=dev)
+    src = torch.randn((2, shape_in[1], shape_in[0]), dtype=torch.float64, device=dev)
+    eager = torch.empty((2, shape_out[1], shape_out[0]), dtype=torch.float64, device=dev)
+    plan.build_tables()
+    plan.execute_rows(src, eager, 0, shape_out[1])
+    torch.cuda.synchronize()
+    replayed = torch.full_like(eager, float("nan"))
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream(dev)
+    n = shape_out[1]
+    with torch.cuda.stream(s):
+        def step():
+            plan.build_tables()
+            plan.execute_rows(src, replayed, 1, n - 2)          # interior rows ...
+            plan.execute_rows(src, replayed, 0, 1)              # ... then the two boundary rows
+            plan.execute_rows(src, replayed, n - 1, 1)
+        step()
+        torch.cuda.synchronize()
+        replayed.fill_(float("nan"))
+        with torch.cuda.graph(g, stream=s):
+            step()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(replayed.view(torch.int64), eager.view(torch.int64))
+    src.mul_(-0.5)                                              # same buffers, new contents: replay again
+    plan.execute_rows(src, eager, 0, n)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(replayed.view(torch.int64), eager.view(torch.int64))
+    plan.close()
