@@ -114,6 +114,29 @@ int main(int argc, char** argv) {
     unsetenv("PXL_REPROJECT_FLAGS");
     g_plan = g_plan_full;
     const size_t bytes = (size_t)NX * NY * NC * 8;
+    if (argc > 2 && strcmp(argv[2], "sweep") == 0) {
+        // ring / tile knobs of the LDS-DMA kernel on ONE arena, destination in the fast-writing half and in the other:
+        // does any setting that lost in round 1's (placement-blind) sweeps win once the placement is held fixed?
+        const size_t pad = ((bytes + (2u << 20) - 1) >> 21) << 21;
+        char* a;
+        CHECK_HIP(hipMalloc(&a, 2 * pad));
+        double* lo = (double*)a; double* hi = (double*)(a + pad);
+        struct { const char* rh; const char* ns; const char* pf; const char* pairs; } cfg[] = {
+            {"16", "8", "3", "2"}, {"16", "4", "3", "2"}, {"16", "16", "3", "2"}, {"16", "8", "1", "2"}, {"16", "8", "2", "2"}, {"16", "8", "5", "2"},
+            {"16", "16", "7", "2"}, {"32", "8", "3", "2"}, {"8", "8", "3", "2"}, {"16", "8", "3", "1"}, {"16", "4", "2", "1"}, {"16", "8", "3", "4"}, {"32", "4", "2", "2"}};
+        for (int rep = 0; rep < trials; ++rep)
+            for (auto& c : cfg) {
+                setenv("PXL_REPROJECT_RH", c.rh, 1); setenv("PXL_REPROJECT_NS", c.ns, 1); setenv("PXL_REPROJECT_PF", c.pf, 1); setenv("PXL_REPROJECT_PAIRS", c.pairs, 1);
+                pxl_reproject_plan* pl;
+                CHECK_PXL(pxl_reproject_plan_create(&win, shape_in, 0, NY, &wout, shape_out, 0, NY, &pl));
+                g_plan = pl;
+                printf("{\"how\": \"knob sweep\", \"rep\": %d, \"RH\": %s, \"NS\": %s, \"PF\": %s, \"PAIRS\": %s, \"dst_above_ms\": %.4f, \"dst_below_ms\": %.4f}\n",
+                       rep, c.rh, c.ns, c.pf, c.pairs, time_kernel(lo, hi), time_kernel(hi, lo));
+                fflush(stdout);
+                pxl_reproject_plan_destroy(pl);
+            }
+        return 0;
+    }
     for (int t = 0; t < trials; ++t) {
         {   // two hipMalloc calls, source first (what bench.py / torch do)
             double *src, *dst;
