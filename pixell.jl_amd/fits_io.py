@@ -87,6 +87,38 @@ def _chunk_bytes():
     return max(4096, int(float(os.environ.get("PXL_FITS_CHUNK_MB", "128")) * (1 << 20)) & ~4095)
 
 
+def _io_threads():
+    """Host threads that move one chunk between the file and the pinned buffer (os.preadv / os.pwritev release the
+    GIL).  Measured on a 5.6 GB map, page-cache-warm file (profiles/r02_fits_io.json): read_map 21.6 GB/s with one
+    thread, 45-48 with four (PCIe Gen5 x16 territory), 32-41 with eight; write_map stays at ~10.5 GB/s whatever the
+    thread count (fresh page-cache pages).  PXL_FITS_THREADS overrides."""
+    v = os.environ.get("PXL_FITS_THREADS")
+    return max(1, int(v)) if v else max(1, min(4, (os.cpu_count() or 2) // 2))
+
+
+def _parallel_io(pool, fn, fd, view, offset, nbytes, nthreads):
+    """fn = os.preadv or os.pwritev on [offset, offset + nbytes) of fd against view[:nbytes], split over the pool in
+    4 KiB-aligned pieces.  Returns the number of bytes moved."""
+    if nthreads <= 1 or nbytes < (8 << 20):
+        piece = [(0, nbytes)]
+    else:
+        step = ((nbytes + nthreads - 1) // nthreads + 4095) & ~4095
+        piece = [(a, min(step, nbytes - a)) for a in range(0, nbytes, step)]
+
+    def run(a, m):
+        done = 0
+        while done < m:                      # short reads / writes are legal
+            k = fn(fd, [view[a + done:a + m]], offset + a + done)
+            if k <= 0:
+                break
+            done += k
+        return done
+
+    if len(piece) == 1:
+        return run(*piece[0])
+    return sum(f.result() for f in [pool.submit(run, a, m) for a, m in piece])
+
+
 class _Stager:
     """Two pinned host buffers + two device staging buffers + a copy stream (double buffering)."""
 
@@ -129,13 +161,14 @@ def _read_spans(path, spans, out, bitpix, dev):
     cur = torch.cuda.current_stream(dev)
     s = C.c_void_p(cur.cuda_stream)
     osz = out.element_size()
-    with open(path, "rb", buffering=0) as f, torch.cuda.device(dev):
+    from concurrent.futures import ThreadPoolExecutor
+    nthr = _io_threads()
+    with open(path, "rb", buffering=0) as f, torch.cuda.device(dev), ThreadPoolExecutor(max_workers=nthr) as pool:
         for i, (off, n, dst) in enumerate(_spans_to_chunks(spans, esz, chunk)):
             b = i & 1
             if st.busy[b] is not None:
                 st.busy[b].synchronize()          # the copy and the decode that used this pair are done
-            f.seek(off)
-            got = f.readinto(st.view[b][:n * esz])
+            got = _parallel_io(pool, os.preadv, f.fileno(), st.view[b], off, n * esz, nthr)
             if got != n * esz:
                 raise ValueError("truncated FITS data block in %s" % path)
             with torch.cuda.stream(st.copy_stream):
@@ -306,8 +339,12 @@ def write_map(path, m: Enmap, extra_cards=()):
     dev = data.device
     flat = data.reshape(-1)
     lib = _lib.load()
-    with open(path, "wb") as f:
-        f.write(header.encode("ascii"))
+    from concurrent.futures import ThreadPoolExecutor
+    nthr = _io_threads()
+    hbytes = header.encode("ascii")
+    with open(path, "wb", buffering=0) as f, ThreadPoolExecutor(max_workers=nthr) as pool:
+        f.write(hbytes)
+        fpos = len(hbytes)                          # file offset of the next data byte
         if n:
             chunk = min(_chunk_bytes() // esz, n)
             st = _Stager(dev, chunk * esz)
@@ -332,9 +369,13 @@ def write_map(path, m: Enmap, extra_cards=()):
                     if pending is not None:         # write chunk i-1 while chunk i is encoded and copied
                         pb, pbytes, pev = pending
                         pev.synchronize()
-                        f.write(st.view[pb][:pbytes])
+                        if _parallel_io(pool, os.pwritev, f.fileno(), st.view[pb], fpos, pbytes, nthr) != pbytes:
+                            raise OSError("short write to %s" % path)
+                        fpos += pbytes
                     pending = (b, m * esz, arrived)
                 pb, pbytes, pev = pending
                 pev.synchronize()
-                f.write(st.view[pb][:pbytes])
-        f.write(b"\0" * (-(n * esz) % BLOCK))
+                if _parallel_io(pool, os.pwritev, f.fileno(), st.view[pb], fpos, pbytes, nthr) != pbytes:
+                    raise OSError("short write to %s" % path)
+                fpos += pbytes
+        os.pwrite(f.fileno(), b"\0" * (-(n * esz) % BLOCK), fpos)
