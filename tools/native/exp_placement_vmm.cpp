@@ -114,6 +114,22 @@ int main(int argc, char** argv) {
     unsetenv("PXL_REPROJECT_FLAGS");
     g_plan = g_plan_full;
     const size_t bytes = (size_t)NX * NY * NC * 8;
+    if (argc > 2 && strcmp(argv[2], "pmc") == 0) {
+        // for rocprofv3 --pmc: one arena; stores only into the high half, then into the low half (10 timed launches each
+        // after fill + 3 warm-ups: the dispatches of k_reproject_dma come in that order); the times are printed so that
+        // the counter rows can be told apart
+        const size_t pad = ((bytes + (2u << 20) - 1) >> 21) << 21;
+        char* a;
+        CHECK_HIP(hipMalloc(&a, 2 * pad));
+        double* lo = (double*)a; double* hi = (double*)(a + pad);
+        g_plan = g_plan_stores;
+        for (int rep = 0; rep < trials; ++rep) {
+            printf("{\"how\": \"pmc run, STORES ONLY to the high half\", \"rep\": %d, \"kernel_ms\": %.4f}\n", rep, time_kernel(lo, hi));
+            printf("{\"how\": \"pmc run, STORES ONLY to the low half\", \"rep\": %d, \"kernel_ms\": %.4f}\n", rep, time_kernel(hi, lo));
+            fflush(stdout);
+        }
+        return 0;
+    }
     if (argc > 2 && strcmp(argv[2], "sweep") == 0) {
         // ring / tile knobs of the LDS-DMA kernel on ONE arena, destination in the fast-writing half and in the other:
         // does any setting that lost in round 1's (placement-blind) sweeps win once the placement is held fixed?
