@@ -236,6 +236,21 @@ __global__ __launch_bounds__(256) void k_reproject_generic_tiled(GenericParams p
 #ifndef PXL_SUNR
 #define PXL_SUNR 4
 #endif
+// sky2pix(safe=true) of one point for the samplers.  The branch-free rewind covers every finite input with a sane
+// period (bit-identical to rewind(), see pxl_device.h); the library-fmod form is kept OUT of line, so that the
+// kernels carry one copy of it instead of eight inlined ones (k_sample_pairs: 120 -> VGPRs, 75 spilled SGPRs before).
+__device__ __noinline__ void sample_coords_slow(Sky2Pix s, double a, double d, double* x, double* y) {
+    *x = s2p_x(s, a); *y = s2p_y(s, d);
+}
+__device__ inline void sample_coords(const Sky2Pix& s, double a, double d, double* x, double* y) {
+    if (s.safe && s.form != PXL_FORM_DIV) {
+        bool ok0, ok1;
+        *x = rewind_try(s.c.ia0 + (a - s.c.a0) * s.rda, s.px, s.cx, s.rpx, &ok0);
+        *y = rewind_try(s.c.id0 + (d - s.c.d0) * s.rdd, s.py, s.cy, s.rpy, &ok1);
+        if (__builtin_expect(ok0 && ok1, 1)) return;
+    }
+    sample_coords_slow(s, a, d, x, y);
+}
 template <typename T>
 __global__ __launch_bounds__(256) void k_sample_bilinear(Sky2Pix s, const T* __restrict__ src, int64_t nx,
                                                          int64_t ny, int32_t nc, int64_t row0, int64_t nrows,
@@ -255,7 +270,8 @@ __global__ __launch_bounds__(256) void k_sample_bilinear(Sky2Pix s, const T* __r
         bool fin[PXL_SUNR];
 #pragma unroll
         for (int u = 0; u < PXL_SUNR; ++u) {
-            double x = s2p_x(s, ad[u].x), y = s2p_y(s, ad[u].y);
+            double x, y;
+            sample_coords(s, ad[u].x, ad[u].y, &x, &y);
             fin[u] = isfinite(x) && isfinite(y);
             int32_t i0, j0;
             split_cell(x, &i0, &fx[u]);
@@ -277,10 +293,19 @@ __global__ __launch_bounds__(256) void k_sample_bilinear(Sky2Pix s, const T* __r
             double m00[PXL_SUNR], m10[PXL_SUNR], m01[PXL_SUNR], m11[PXL_SUNR];
 #pragma unroll
             for (int u = 0; u < PXL_SUNR; ++u) {
-                m00[u] = o00[u] >= 0 ? (double)pl[o00[u]] : 0.0;
-                m10[u] = o10[u] >= 0 ? (double)pl[o10[u]] : 0.0;
-                m01[u] = o01[u] >= 0 ? (double)pl[o01[u]] : 0.0;
-                m11[u] = o11[u] >= 0 ? (double)pl[o11[u]] : 0.0;
+                // unconditional loads (an off-map tap reads element 0 and is zeroed afterwards): no exec juggling
+                // between the gathers
+                m00[u] = (double)pl[o00[u] >= 0 ? o00[u] : 0];
+                m10[u] = (double)pl[o10[u] >= 0 ? o10[u] : 0];
+                m01[u] = (double)pl[o01[u] >= 0 ? o01[u] : 0];
+                m11[u] = (double)pl[o11[u] >= 0 ? o11[u] : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < PXL_SUNR; ++u) {
+                m00[u] = o00[u] >= 0 ? m00[u] : 0.0;
+                m10[u] = o10[u] >= 0 ? m10[u] : 0.0;
+                m01[u] = o01[u] >= 0 ? m01[u] : 0.0;
+                m11[u] = o11[u] >= 0 ? m11[u] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < PXL_SUNR; ++u) {
@@ -350,7 +375,8 @@ __global__ __launch_bounds__(256) void k_sample_pairs(Sky2Pix s, const typename 
         bool fin[SUNR];
 #pragma unroll
         for (int u = 0; u < SUNR; ++u) {
-            double x = s2p_x(s, ad[u].x), y = s2p_y(s, ad[u].y);
+            double x, y;
+            sample_coords(s, ad[u].x, ad[u].y, &x, &y);
             fin[u] = isfinite(x) && isfinite(y);
             int32_t i0, j0;
             split_cell(x, &i0, &fx[u]);
@@ -369,9 +395,15 @@ __global__ __launch_bounds__(256) void k_sample_pairs(Sky2Pix s, const typename 
             T2 a[SUNR], b[SUNR];
 #pragma unroll
             for (int u = 0; u < SUNR; ++u) {
-                T2 z; z.x = (T)0; z.y = (T)0;
-                a[u] = oa[u] >= 0 ? pl[oa[u]] : z;
-                b[u] = ob[u] >= 0 ? pl[ob[u]] : z;
+                // unconditional whole-entry loads (a conditional one became four 8-byte FLAT loads through a select
+                // between the entry and a zero on the stack); an off-map entry reads entry 0 and is zeroed afterwards
+                a[u] = pl[oa[u] >= 0 ? oa[u] : 0];
+                b[u] = pl[ob[u] >= 0 ? ob[u] : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < SUNR; ++u) {
+                if (oa[u] < 0) { a[u].x = (T)0; a[u].y = (T)0; }
+                if (ob[u] < 0) { b[u].x = (T)0; b[u].y = (T)0; }
             }
 #pragma unroll
             for (int u = 0; u < SUNR; ++u) {
