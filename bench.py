@@ -517,12 +517,12 @@ def bench_scattered(args, rank, world, dev):
     wref = wcs.to_struct()
     shp = pj._lib.shape_arr((nx, ny, 1))
 
-    # PXL_BENCH_SAMPLER=pairs (default when a rank has >= 8e8 points): every step re-lays the map into row pairs (one streaming pass, inside the
-    # timed step) and samples from that copy -- ~1.25 instead of ~2.25 random sectors per point; "direct" = 4 taps
-    # straight from the Julia-layout map.  Both give the same bits.
+    # PXL_BENCH_SAMPLER=pairs (default when a rank has >= 3e8 points): every step re-lays the map into sector-grouped row
+    # pairs (one streaming pass, inside the timed step) and samples from that copy -- 1.0 instead of ~2.25 random sectors
+    # per point; "direct" = 4 taps straight from the Julia-layout map.  Both give the same bits.
     mode = os.environ.get("PXL_BENCH_SAMPLER", "auto")
-    if mode == "auto":      # the per-step re-layout (~4 ms, constant per rank) only pays for itself on a large batch
-        mode = "pairs" if n >= 8e8 else "direct"
+    if mode == "auto":      # the per-step re-layout (~5 ms, constant per rank; 23 ps saved per point) only pays on a large batch
+        mode = "pairs" if n >= 3e8 else "direct"
     pairs = torch.empty(lib.pxl_sample_pairs_elems(shp, ny), dtype=torch.float64, device=dev) if mode == "pairs" else None
 
     def step(k, ev=None):

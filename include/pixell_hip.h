@@ -233,11 +233,14 @@ int pxl_sample_car_bilinear_f32(const pxl_car_wcs* wcs_in, const int64_t shape_i
                                 int64_t src_row0, int64_t src_nrows,
                                 int64_t n, const double* sky2xN, float* out, void* stream);
 
-/* ---- The same sample from a ROW-PAIR copy of the map (caller-owned, pxl_sample_pairs_elems() map elements =
- *      twice the resident window plus one row): entry (p, i) holds (v[p-1][i], v[p][i]), so a point's 2x2
- *      neighbourhood is two adjacent entries -- about 1.25 instead of 2.25 random 64-byte sectors per point.
- *      Build once per map (one streaming pass), sample any number of batches; results are bit-identical to
- *      pxl_sample_car_bilinear_*.  No reference counterpart (the reference has no sampler).     */
+/* ---- The same sample from a ROW-PAIR copy of the map (caller-owned, 64-byte aligned, pxl_sample_pairs_elems() map
+ *      elements = 8/3 of the resident window plus one row): an entry holds (v[p-1][i], v[p][i]), and the entries of a
+ *      row are stored in 64-byte groups that overlap by one entry (4 Float64 / 8 Float32 entries per group, columns
+ *      past nx wrapping round), so a point's whole 2x2 neighbourhood is two adjacent entries of ONE 64-byte sector:
+ *      1.0 instead of 2.25 random sectors per point.  The element count covers either element type (a Float32 copy
+ *      of a large map uses 6/7 of it).  Build once per map (one streaming pass), sample any number of batches; results are
+ *      bit-identical to pxl_sample_car_bilinear_*.  No reference counterpart (the reference has no sampler,
+ *      SURVEY 8(a) R1).                                                                                          */
 int64_t pxl_sample_pairs_elems(const int64_t shape_in[3], int64_t src_nrows);      /* -1 on invalid arguments */
 int pxl_sample_build_pairs_f64(const int64_t shape_in[3], const double* src, int64_t src_nrows, double* pairs,
                                void* stream);

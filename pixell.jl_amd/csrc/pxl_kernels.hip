@@ -1073,17 +1073,23 @@ int64_t pxl_sample_pairs_elems(const int64_t shape_in[3], int64_t src_nrows) {
         fail(PXL_EINVAL, "sample_pairs_elems: invalid shape or window");
         return -1;
     }
-    return 2 * shape_in[0] * (src_nrows + 1) * shape_in[2];
+    // one size for both element types: Float64 rows (groups of 4 entries, 3 new columns each) are the longer ones except
+    // on maps of a few columns, where the rounding up to whole groups can favour Float32 (8 entries, 7 new columns)
+    const int64_t e64 = PairGroup<double>::groups(shape_in[0]) * PairGroup<double>::E;
+    const int64_t e32 = PairGroup<float>::groups(shape_in[0]) * PairGroup<float>::E;
+    return 2 * (e64 > e32 ? e64 : e32) * (src_nrows + 1) * shape_in[2];
 }
 
 static int build_pairs_impl(const int64_t shape_in[3], const void* src, int64_t src_nrows, void* pairs, void* stream, int dtype) {
     if (pxl_sample_pairs_elems(shape_in, src_nrows) < 0) return PXL_EINVAL;
     if (!pairs || (!src && src_nrows > 0)) return fail(PXL_EINVAL, "sample_build_pairs: null buffer");
-    if (((uintptr_t)pairs & (2 * dtype - 1)) != 0) return fail(PXL_EINVAL, "sample_build_pairs: pair buffer must be aligned to two elements");
+    if (((uintptr_t)pairs & 63) != 0) return fail(PXL_EINVAL, "sample_build_pairs: pair buffer must be 64-byte aligned");
+    if (shape_in[0] > 0x7fffffffLL) return fail(PXL_EINVAL, "sample_build_pairs: more than 2^31 columns");
     if (shape_in[2] > 65535) return fail(PXL_EINVAL, "sample_build_pairs: more than 65535 components");
     const int64_t nx = shape_in[0], tiles = (src_nrows + 1 + PXL_POS_ROWS - 1) / PXL_POS_ROWS;
     if (tiles > 65535) return fail(PXL_EINVAL, "sample_build_pairs: more than %lld rows per call", 65535LL * PXL_POS_ROWS);
-    dim3 grid((unsigned)((nx + 255) / 256), (unsigned)tiles, (unsigned)shape_in[2]);
+    const int64_t pitch = dtype == 4 ? PairGroup<float>::groups(nx) * PairGroup<float>::E : PairGroup<double>::groups(nx) * PairGroup<double>::E;
+    dim3 grid((unsigned)((pitch + 255) / 256), (unsigned)tiles, (unsigned)shape_in[2]);
     if (dtype == 4)
         hipLaunchKernelGGL((k_build_rowpairs<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, nx, src_nrows, (float2*)pairs);
     else
@@ -1107,7 +1113,8 @@ static int sample_pairs_impl(const pxl_car_wcs* wcs_in, const int64_t shape_in[3
         return fail(PXL_EINVAL, "sample_pairs: source window outside the map");
     if (n < 0 || (n > 0 && (!sky || !out || !pairs))) return fail(PXL_EINVAL, "sample_pairs: null buffer or negative n");
     if (((uintptr_t)sky & 15) != 0) return fail(PXL_EINVAL, "sample_pairs: 2xN buffer must be 16-byte aligned");
-    if (((uintptr_t)pairs & (2 * dtype - 1)) != 0) return fail(PXL_EINVAL, "sample_pairs: pair buffer must be aligned to two elements");
+    if (((uintptr_t)pairs & 63) != 0) return fail(PXL_EINVAL, "sample_pairs: pair buffer must be 64-byte aligned");
+    if (shape_in[0] > 0x7fffffffLL) return fail(PXL_EINVAL, "sample_pairs: more than 2^31 columns");
     if (n == 0) return PXL_OK;
     Sky2Pix s = sky2pix_setup(*wcs_in, shape_in[0], shape_in[1], 1, PXL_FORM_RECIP);
     int periodic = fabs((double)shape_in[0] * fabs(wcs_in->cdelt[0] * wcs_in->unit) - PXL_TWOPI_D) < 1e-8;

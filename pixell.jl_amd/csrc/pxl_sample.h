@@ -322,30 +322,49 @@ __global__ __launch_bounds__(256) void k_sample_bilinear(Sky2Pix s, const T* __r
 // ---- row-pair layout for scattered sampling.  The gather above is bound by random 64-byte sector fetches (about
 // 2.25 per point: the two taps of a row are neighbours, the two rows are nx elements apart).  In the pair layout
 // element (p, i) holds (v[p-1][i], v[p][i]) -- rows outside the resident window read as zero, p = 0 .. nrows -- so
-// the whole 2x2 neighbourhood of a point is two ADJACENT 2-element entries: about 1.25 sectors per point, for
-// twice the map's footprint (288 GB of HBM is there to be used) and one streaming pass to build it.  Same taps,
-// same arithmetic: results are bit-identical to k_sample_bilinear.
+// the whole 2x2 neighbourhood of a point is two ADJACENT 2-element entries, kept inside one sector by the grouping
+// below: one random sector per point, for 8/3 of the map's footprint (288 GB of HBM is there to be used) and one
+// streaming pass to build it.  Same taps, same arithmetic: results are bit-identical to k_sample_bilinear.
+// What bounds it (tools/native/exp_random_reach.cpp, exp_scalar_gather.cpp): the memory system serves ~54 G random
+// 64-byte requests per second whatever the footprint (128 MiB ... 48 GiB, Infinity Cache or HBM, vector and scalar
+// path together), and ~38 G cells/s when the coordinate and result streams share it; this kernel reaches 31-33.
 template <typename T> struct Vec2T;
 template <> struct Vec2T<double> { typedef double2 type; };
 template <> struct Vec2T<float>  { typedef float2 type; };
 
+// Sector grouping: the entries of a pair row are stored in groups of one 64-byte sector (E = 4 Float64 or 8 Float32
+// entries) that OVERLAP by one entry: group s holds columns s*(E-1)+1 ... s*(E-1)+E (1-based; columns past nx wrap
+// round to 1, 2, ... -- the sampler zeroes them on a map that is not periodic).  A cell's two adjacent entries therefore
+// always share a sector: 1.0 random sector per point instead of 1.25 (Float64) / 1.125 (Float32), for 4/3 (8/7) of the
+// plain row-pair footprint.  Measured with the cells forced into one sector: 33.3 -> 30.2 ms per 1e9 points.
+template <typename T> struct PairGroup {
+    static constexpr int E = 64 / (2 * (int)sizeof(T));     // entries per sector
+    static constexpr int C = E - 1;                         // cells (distinct left columns) per sector
+    __host__ __device__ static inline int64_t groups(int64_t nx) { return (nx + C - 1) / C; }
+};
 template <typename T>
 __global__ __launch_bounds__(256) void k_build_rowpairs(const T* __restrict__ src, int64_t nx, int64_t nrows,
                                                         typename Vec2T<T>::type* __restrict__ pairs) {
-    // block = (256 columns, PXL_POS_ROWS pair rows, component): a lane walks down its column carrying the row above
+    // block = (256 entries of a pair row, PXL_POS_ROWS pair rows, component): a lane walks down its column carrying the
+    // row above; stores are contiguous 2-element entries, loads run along the row with every (E-1)-th column read twice
     typedef typename Vec2T<T>::type T2;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nx) return;
+    constexpr int E = PairGroup<T>::E, C = PairGroup<T>::C;
+    const int64_t pitch = PairGroup<T>::groups(nx) * E;               // entries per pair row
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= pitch) return;
+    const int64_t g = t / E, e = t - g * E;
+    int64_t i = g * C + e;                                              // 0-based column
+    if (i >= nx) i %= nx;
     const int64_t c = blockIdx.z;
     const T* pl = src + c * nx * nrows;
-    T2* out = pairs + c * nx * (nrows + 1);
+    T2* out = pairs + c * pitch * (nrows + 1);
     const int64_t p0 = (int64_t)blockIdx.y * PXL_POS_ROWS;
     const int64_t p1 = (p0 + PXL_POS_ROWS <= nrows) ? p0 + PXL_POS_ROWS : nrows + 1;     // pair rows [p0, p1)
     T above = (p0 >= 1) ? pl[(p0 - 1) * nx + i] : (T)0;
     for (int64_t p = p0; p < p1; ++p) {
         const T here = (p < nrows) ? pl[p * nx + i] : (T)0;
         T2 v; v.x = above; v.y = here;
-        out[p * nx + i] = v;
+        out[p * pitch + t] = v;
         above = here;
     }
 }
@@ -361,8 +380,10 @@ __global__ __launch_bounds__(256) void k_sample_pairs(Sky2Pix s, const typename 
                                                       T* __restrict__ out) {
     typedef typename Vec2T<T>::type T2;
     constexpr int SUNR = PairsUnroll<T>::value;
+    constexpr int E = PairGroup<T>::E, C = PairGroup<T>::C;
     const int64_t chunk = (int64_t)blockDim.x * SUNR;
-    const int64_t plane = nx * (nrows + 1);
+    const int64_t pitch = PairGroup<T>::groups(nx) * E;
+    const int64_t plane = pitch * (nrows + 1);
     for (int64_t k0 = (int64_t)blockIdx.x * chunk + threadIdx.x; k0 < n; k0 += (int64_t)gridDim.x * chunk) {
         double2 ad[SUNR];
 #pragma unroll
@@ -387,8 +408,12 @@ __global__ __launch_bounds__(256) void k_sample_pairs(Sky2Pix s, const typename 
             else { oka = (ia >= 1 && ia <= nx); okb = (ib >= 1 && ib <= nx); }
             const int64_t p = (int64_t)j0 - row0;            // entry p holds resident rows p-1 (cell row j0) and p
             const bool rows = (p >= 0 && p <= nrows);
-            oa[u] = (rows && oka) ? p * nx + (ia - 1) : -1;
-            ob[u] = (rows && okb) ? p * nx + (ib - 1) : -1;
+            // entry of column c (1-based, <= nx) in its own group: (c-1)/C * E + (c-1)%C; the right-hand column of a cell
+            // is the next entry of the SAME group (the wrapped column 1 after column nx included)
+            const uint32_t ca = (uint32_t)((oka ? ia : ib) - 1), ga = ca / (uint32_t)C;
+            const int64_t ent = p * pitch + (int64_t)ga * E + (ca - ga * (uint32_t)C);
+            oa[u] = (rows && oka) ? ent : -1;
+            ob[u] = (rows && okb) ? (oka ? ent + 1 : ent) : -1;
         }
         for (int c = 0; c < nc; ++c) {
             const T2* pl = pairs + (int64_t)c * plane;
