@@ -150,6 +150,34 @@ function sample_bilinear(m::Enmap{Float64,N,<:HIPArray,<:AbstractCARWCS}, sky::D
     return out
 end
 
+# ---- the same sample through a row-pair copy of the map (8/3 of its footprint, one random 64-byte sector per point
+#      instead of 2.25: 1.75x faster on a 0.5-arcmin map).  Build once per map, sample any number of batches.
+struct SamplePairs
+    data::HIPArray{Float64,1}
+    wcs::CarWCS
+    shape::Vector{Int64}         # (nx, ny, nc)
+end
+function SamplePairs(m::Enmap{Float64,N,<:HIPArray,<:AbstractCARWCS}) where {N}
+    nc = N == 3 ? size(m, 3) : 1
+    shp = Int64[size(m, 1), size(m, 2), nc]
+    nel = ccall((:pxl_sample_pairs_elems, libpixell_hip), Int64, (Ptr{Int64}, Int64), shp, size(m, 2))
+    nel < 0 && check(Cint(-22))                                   # raises with pxl_last_error()
+    data = HIPArray{Float64}(undef, nel)                       # device allocations are 256-byte aligned
+    src = parent(m)
+    GC.@preserve src data shp check(ccall((:pxl_sample_build_pairs_f64, libpixell_hip), Cint,
+        (Ptr{Int64}, Ptr{Cdouble}, Int64, Ptr{Cdouble}, Ptr{Cvoid}), shp, src.ptr, size(m, 2), data.ptr, NULLSTREAM))
+    return SamplePairs(data, CarWCS(getwcs(m)), shp)
+end
+function sample_bilinear(p::SamplePairs, sky::DevCoords)
+    n = size(sky, 2)
+    out = HIPArray{Float64}(undef, n, Int(p.shape[3]))
+    data = p.data; shp = p.shape
+    GC.@preserve data sky out shp check(ccall((:pxl_sample_car_bilinear_pairs_f64, libpixell_hip), Cint,
+        (Ref{CarWCS}, Ptr{Int64}, Ptr{Cdouble}, Int64, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cvoid}),
+        p.wcs, shp, data.ptr, 0, shp[2], n, sky.ptr, out.ptr, NULLSTREAM))
+    return out
+end
+
 # ---- pixareamap! (enmap_ops.jl:124-138) and unwind! / rewind! (enmap_ops.jl:15-32) on device arrays
 function Pixell.pixareamap!(pixareas::Enmap{Float64,2,<:HIPArray,<:AbstractCARWCS})
     shp = Int64[size(pixareas, 1), size(pixareas, 2)]
@@ -213,6 +241,6 @@ sharded_step!(dst, plan, src, own_rows, sends, recvs, comm::PxlComm) = sharded_s
 comm_destroy(c::PxlComm) = check(ccall((:pxl_comm_destroy, libpixell_hip), Cint, (Ptr{Cvoid},), c.handle))
 comm_backend() = unsafe_string(ccall((:pxl_comm_backend, libpixell_hip), Cstring, ()))
 
-export HIPArray, posmap_device, reproject, reproject!, ReprojectPlan, sample_bilinear, HaloXfer, sharded_step!
+export HIPArray, posmap_device, reproject, reproject!, ReprojectPlan, sample_bilinear, SamplePairs, HaloXfer, sharded_step!
 export PxlComm, comm_unique_id, comm_init_rank, comm_destroy, comm_backend
 end # module

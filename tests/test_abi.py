@@ -34,6 +34,24 @@ def test_library_exports_every_declared_symbol(pj):
     assert sorted(pj._lib.SIGNATURES) == declared_symbols()
 
 
+def test_julia_binding_only_calls_declared_symbols(pj):
+    """julia/PixellHIP.jl (the binding a Pixell.jl maintainer would add) must ccall entry points that the
+    header declares and the library exports, with as many argument types as the C prototype has parameters."""
+    text = open(os.path.join(ROOT, "julia", "PixellHIP.jl")).read()
+    header = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    lib = ctypes.CDLL(pj.library_path())
+    calls = re.findall(r"ccall\(\(:(pxl_[a-z0-9_]+), libpixell_hip\),\s*\w+,\s*\(([^)]*)\)", text, flags=re.S)
+    assert len(calls) >= 20
+    declared = declared_symbols()
+    for name, argtypes in calls:
+        assert name in declared, "PixellHIP.jl calls %s, which include/pixell_hip.h does not declare" % name
+        assert hasattr(lib, name)
+        proto = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, header, flags=re.S).group(1)
+        nparams = 0 if proto.strip() in ("", "void") else len(proto.split(","))
+        nargs = len([a for a in argtypes.split(",") if a.strip()])
+        assert nargs == nparams, "%s: %d Julia argument types for %d C parameters" % (name, nargs, nparams)
+
+
 def test_version_and_error_channel_without_gpu(pj):
     lib = pj.load_library()
     assert lib.pxl_version() == 100
