@@ -125,7 +125,8 @@ def cpu_baseline_reproject(shape_in, wcs_in, shape_out, wcs_out, budget_s=12.0):
 def place_buffers(sh, candidates, dev, keep="first", arena=False):
     """Allocate and fill the resident maps.  Where the driver puts a 20 GB buffer physically moves this
     HBM-bound kernel by up to 10 % (profiles/README.md: same virtual addresses, re-allocated, 7.35-8.13 ms).
-    The headline number comes from the FIRST allocation (what a job gets without steering anything).  With
+    The headline number comes from the FIRST allocation, made by the fixed policy of DecStripReprojector.alloc_pair (one
+    allocation, destination above the source; --two-allocations for two separate ones).  With
     --placements N > 1 the other N - 1 allocations are only probed (4 launches each, outside every timed step) so
     that the line can say where the first one sits in the spread (roofline.frac_first/median/best_placement);
     --keep-placement best restores round 1's behaviour of running the timed steps on the fastest candidate."""
@@ -167,7 +168,7 @@ def place_buffers(sh, candidates, dev, keep="first", arena=False):
             torch.cuda.empty_cache()
     del ballast
     torch.cuda.empty_cache()
-    return best[0], best[1], {"allocation": "one arena, dst above src" if arena else "two allocations", "candidates_ms": tried,
+    return best[0], best[1], {"allocation": "one allocation, destination above the source (DecStripReprojector.alloc_pair: fixed policy, nothing probed)" if arena else "two allocations", "candidates_ms": tried,
                               "chosen_ms": round(best[2], 4), "chosen": keep,
                               "first_ms": tried[0], "median_ms": sorted(tried)[len(tried) // 2], "best_ms": min(tried)}
 
@@ -195,10 +196,13 @@ def main():
     ap.add_argument("--placements", type=int, default=int(os.environ.get("PXL_BENCH_PLACEMENTS", "1")),
                     help="buffer placements probed at setup (default 1: just the first allocation, which is what the "
                          "headline always reports unless --keep-placement best)")
-    ap.add_argument("--arena", action="store_true",
-                    help="carve the source and destination maps out of ONE allocation, destination above the source (default: "
-                         "two separate allocations, what any caller gets; where the destination lands physically moves the "
-                         "kernel by up to 8 %% either way -- DESIGN 9 item 6)")
+    ap.add_argument("--arena", dest="arena", action="store_true", default=os.environ.get("PXL_BENCH_ARENA", "1") != "0",
+                    help="(default) carve the source and destination maps out of ONE allocation, destination above the source: "
+                         "DecStripReprojector.alloc_pair, a fixed policy any caller can use, nothing probed.  Where the destination "
+                         "lands physically moves the kernel by up to 10 %% (DESIGN 9 item 6): this arrangement gave the fast case in "
+                         "20 of 21 processes on 7 boxes, two separate allocations in about half")
+    ap.add_argument("--two-allocations", dest="arena", action="store_false",
+                    help="allocate the source and the destination separately (round 1's and early round 2's default)")
     ap.add_argument("--keep-placement", default="first", choices=["first", "best"],
                     help="which probed placement the timed steps run on (first = unselected headline)")
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the output of the timed run is always "
