@@ -369,10 +369,9 @@ __global__ __launch_bounds__(256) void k_build_rowpairs(const T* __restrict__ sr
     }
 }
 
-// points per lane per trip of k_sample_pairs: Float32 entries (8 B) run 17 % faster with 2 than with 4 on the
-// 0.5-arcmin map (29.5 vs 25.2 Gpts/s, same-box A/B); Float64 is indifferent
+// points per lane per trip of k_sample_pairs: the kernel is bound by the random-request rate of the memory system, not
+// by loads in flight -- Float64: 2, 4 and 8 within 3 %; Float32 entries: 29.8 / 28.9 / 27.8 ms per 1e9 points with 1 / 2 / 4
 template <typename T> struct PairsUnroll { static constexpr int value = PXL_SUNR; };
-template <> struct PairsUnroll<float> { static constexpr int value = 2; };
 template <typename T>
 __global__ __launch_bounds__(256) void k_sample_pairs(Sky2Pix s, const typename Vec2T<T>::type* __restrict__ pairs,
                                                       int64_t nx, int64_t ny, int32_t nc, int64_t row0, int64_t nrows,

@@ -797,6 +797,14 @@ def test_sample_row_pair_layout(pj, O, dev):
     m = pj.Enmap(torch.zeros((shape[1], shape[0]), dtype=torch.float64, device=dev), wcs)
     with pytest.raises(ValueError):
         pj.SamplePairs(m, out=torch.empty(10, dtype=torch.float64, device=dev))
+    # ... and so is one that does not start on a 64-byte sector (the layout keeps every cell inside one sector)
+    lib = pj.load_library()
+    need = lib.pxl_sample_pairs_elems(pj._lib.shape_arr((shape[0], shape[1], 1)), shape[1])
+    assert need == 2 * 4 * ((shape[0] + 2) // 3) * (shape[1] + 1)              # groups of 4 entries, 3 new columns each
+    with pytest.raises(pj.PixellHipError, match="64-byte"):
+        pj.SamplePairs(m, out=torch.empty(need + 8, dtype=torch.float64, device=dev)[1:need + 1])
+    # tiny maps: a Float32 row (groups of 8 entries, 7 new columns) can be the longer one
+    assert lib.pxl_sample_pairs_elems(pj._lib.shape_arr((8, 8, 2)), 4) == 2 * 16 * 5 * 2
 
 
 def test_sample_binned_plan(pj, O, dev, monkeypatch):

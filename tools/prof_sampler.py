@@ -14,6 +14,8 @@ modes = os.environ.get("PXL_MODES", "direct,pairs").split(",")
 shape, wcs = pj.fullsky_geometry(2 * math.pi / int(os.environ.get("PXL_NX", "43200")))
 data = torch.empty((shape[1], shape[0]), dtype=torch.float64, device=dev)
 pj.fill_random_(data, 1234, 0, "normal")
+if os.environ.get("PXL_F32", "0") == "1":          # a Float32 map (PXL_F32=1)
+    data = data.to(torch.float32)
 m = pj.Enmap(data, wcs)
 sky = torch.empty((n, 2), dtype=torch.float64, device=dev)
 pj.fill_sphere_points_(sky, 42)
