@@ -238,7 +238,8 @@ __global__ __launch_bounds__(256) void k_reproject_generic_tiled(GenericParams p
 #endif
 // sky2pix(safe=true) of one point for the samplers.  The branch-free rewind covers every finite input with a sane
 // period (bit-identical to rewind(), see pxl_device.h); the library-fmod form is kept OUT of line, so that the
-// kernels carry one copy of it instead of eight inlined ones (k_sample_pairs: 120 -> VGPRs, 75 spilled SGPRs before).
+// row-pair kernel carries one copy of it instead of eight inlined ones (either form runs it at the same speed; the direct
+// kernel keeps the inlined form, see there).
 __device__ __noinline__ void sample_coords_slow(Sky2Pix s, double a, double d, double* x, double* y) {
     *x = s2p_x(s, a); *y = s2p_y(s, d);
 }
@@ -270,8 +271,10 @@ __global__ __launch_bounds__(256) void k_sample_bilinear(Sky2Pix s, const T* __r
         bool fin[PXL_SUNR];
 #pragma unroll
         for (int u = 0; u < PXL_SUNR; ++u) {
-            double x, y;
-            sample_coords(s, ad[u].x, ad[u].y, &x, &y);
+            // inlined evaluators here (fast path + library fmod per coordinate): the out-of-line fallback of
+            // sample_coords() buys this kernel a fourth wave per SIMD and costs it 15 % (48.6-50.2 vs 55.9-57.3 ms per 1e9
+            // points, same box) -- with four separate taps per point more waves in flight evict each other's sectors
+            double x = s2p_x(s, ad[u].x), y = s2p_y(s, ad[u].y);
             fin[u] = isfinite(x) && isfinite(y);
             int32_t i0, j0;
             split_cell(x, &i0, &fx[u]);
