@@ -294,21 +294,26 @@ __global__ __launch_bounds__(256) void k_sample_bilinear(Sky2Pix s, const T* __r
         for (int c = 0; c < nc; ++c) {
             const T* pl = src + (int64_t)c * plane;
             double m00[PXL_SUNR], m10[PXL_SUNR], m01[PXL_SUNR], m11[PXL_SUNR];
+            // interior points (all four taps on the map, the two columns adjacent): ONE 2-element load per row (element-
+            // aligned only; 54.9 vs 57.8 ms per 1e9 points against four separate taps, same box); the rest (seam, edges, rows
+            // outside the window) take the four taps in a rare branch
+            struct __attribute__((packed, aligned(sizeof(T)))) TT { T a, b; };
+            bool wide[PXL_SUNR];
 #pragma unroll
             for (int u = 0; u < PXL_SUNR; ++u) {
-                // unconditional loads (an off-map tap reads element 0 and is zeroed afterwards): no exec juggling
-                // between the gathers
-                m00[u] = (double)pl[o00[u] >= 0 ? o00[u] : 0];
-                m10[u] = (double)pl[o10[u] >= 0 ? o10[u] : 0];
-                m01[u] = (double)pl[o01[u] >= 0 ? o01[u] : 0];
-                m11[u] = (double)pl[o11[u] >= 0 ? o11[u] : 0];
+                wide[u] = o00[u] >= 0 && o01[u] >= 0 && o10[u] == o00[u] + 1 && o11[u] == o01[u] + 1;
+                const TT ra = *reinterpret_cast<const TT*>(pl + (wide[u] ? o00[u] : 0));
+                const TT rb = *reinterpret_cast<const TT*>(pl + (wide[u] ? o01[u] : 0));
+                m00[u] = (double)ra.a; m10[u] = (double)ra.b; m01[u] = (double)rb.a; m11[u] = (double)rb.b;
             }
 #pragma unroll
             for (int u = 0; u < PXL_SUNR; ++u) {
-                m00[u] = o00[u] >= 0 ? m00[u] : 0.0;
-                m10[u] = o10[u] >= 0 ? m10[u] : 0.0;
-                m01[u] = o01[u] >= 0 ? m01[u] : 0.0;
-                m11[u] = o11[u] >= 0 ? m11[u] : 0.0;
+                if (__builtin_expect(!wide[u], 0)) {
+                    m00[u] = o00[u] >= 0 ? (double)pl[o00[u]] : 0.0;
+                    m10[u] = o10[u] >= 0 ? (double)pl[o10[u]] : 0.0;
+                    m01[u] = o01[u] >= 0 ? (double)pl[o01[u]] : 0.0;
+                    m11[u] = o11[u] >= 0 ? (double)pl[o11[u]] : 0.0;
+                }
             }
 #pragma unroll
             for (int u = 0; u < PXL_SUNR; ++u) {
