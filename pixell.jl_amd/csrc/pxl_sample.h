@@ -240,17 +240,25 @@ __global__ __launch_bounds__(256) void k_reproject_generic_tiled(GenericParams p
 // period (bit-identical to rewind(), see pxl_device.h); the library-fmod form is kept OUT of line, so that the
 // row-pair kernel carries one copy of it instead of eight inlined ones (either form runs it at the same speed; the direct
 // kernel keeps the inlined form, see there).
-__device__ __noinline__ void sample_coords_slow(Sky2Pix s, double a, double d, double* x, double* y) {
-    *x = s2p_x(s, a); *y = s2p_y(s, d);
+// (arguments and result in registers: with the struct passed by value every lane stored its 144 bytes to scratch on
+// every trip, fast path or not -- 8.5 GB of HBM writes per 1e9 points in WRITE_SIZE)
+__device__ __noinline__ double2 sample_coords_slow(double a, double d, double ia0, double a0, double rda, double px, double cx,
+                                                   double rpx, double id0, double d0, double rdd, double py, double cy, double rpy) {
+    // safe = 1, reciprocal form (the only one the samplers use): s2p_x / s2p_y of pxl_device.h with the library fmod
+    return make_double2(rewind(ia0 + (a - a0) * rda, px, cx, rpx), rewind(id0 + (d - d0) * rdd, py, cy, rpy));
 }
 __device__ inline void sample_coords(const Sky2Pix& s, double a, double d, double* x, double* y) {
     if (s.safe && s.form != PXL_FORM_DIV) {
         bool ok0, ok1;
         *x = rewind_try(s.c.ia0 + (a - s.c.a0) * s.rda, s.px, s.cx, s.rpx, &ok0);
         *y = rewind_try(s.c.id0 + (d - s.c.d0) * s.rdd, s.py, s.cy, s.rpy, &ok1);
-        if (__builtin_expect(ok0 && ok1, 1)) return;
+        if (__builtin_expect(!(ok0 && ok1), 0)) {
+            const double2 r = sample_coords_slow(a, d, s.c.ia0, s.c.a0, s.rda, s.px, s.cx, s.rpx, s.c.id0, s.c.d0, s.rdd, s.py, s.cy, s.rpy);
+            *x = r.x; *y = r.y;
+        }
+        return;
     }
-    sample_coords_slow(s, a, d, x, y);
+    *x = s2p_x(s, a); *y = s2p_y(s, d);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void k_sample_bilinear(Sky2Pix s, const T* __restrict__ src, int64_t nx,
