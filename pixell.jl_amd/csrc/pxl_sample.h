@@ -197,7 +197,9 @@ __global__ __launch_bounds__(256) void k_reproject_generic_tiled(GenericParams p
     const int64_t tile = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
     const int64_t ti0 = (int64_t)blockIdx.x * 64, tj0 = (int64_t)blockIdx.y * PXL_TH;   // 0-based tile origin
     const int tid = threadIdx.x;
-    const int cx = tid & 63, ry = tid >> 6;
+    // ry through readfirstlane: the row weights c_tile_weights.wy[ry + 4q] are then wave-uniform SCALAR loads; as plain
+    // tid >> 6 they were three 16-byte VECTOR loads per pixel, a dependent L1 round trip in front of every pixel's taps
+    const int cx = tid & 63, ry = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t i = ti0 + cx;
     if (i >= p.nxo) return;
     if (flag[tile]) return;                      // k_reproject_generic_exact_tiles does this tile
