@@ -208,8 +208,8 @@ int pxl_reproject_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shap
 
 /* ---- Generic (non-separable) bilinear reprojection between CAR and Gnomonic maps: per output pixel
  *      pix2sky(out) -> sky2pix(in) -> 2x2 gather, with the evaluators of car_proj.jl / tan_proj.jl.
- *      The coordinate map is interpolated per 64 x 32 output tile (degree 5 x 5 from 36 exact evaluations) and the
- *      interpolant checked against exact evaluations to 1e-10 pixel; tiles that fail the check (and every tile with
+ *      The coordinate map is interpolated per 128 x 32 output tile (degree 6 x 5 from 42 exact evaluations) and the
+ *      interpolant checked against twelve more exact evaluations to 1e-10 pixel; tiles that fail the check (and every tile with
  *      PXL_GENERIC_EXACT=1) evaluate per pixel (~10 FP64 libm calls each).  Full maps only.
  *      proj codes: PXL_PROJ_CAR, PXL_PROJ_TAN.                                                                   */
 #define PXL_PROJ_CAR 0
@@ -218,7 +218,7 @@ int pxl_reproject_generic_bilinear_f64(const pxl_car_wcs* wcs_in, int proj_in, c
                                        const double* src, const pxl_car_wcs* wcs_out, int proj_out,
                                        const int64_t shape_out[2], double* dst, void* stream);
 
-/* diagnostics: of the 64 x 32 output tiles of the last pxl_reproject_generic_bilinear_f64 call on the current device,
+/* diagnostics: of the 128 x 32 output tiles of the last pxl_reproject_generic_bilinear_f64 call on the current device,
  * how many evaluated the coordinates per pixel (the interpolant failed its 1e-10-pixel check there: the rewind jump of
  * a periodic source, the Gnomonic horizon, very coarse pixels).  Synchronises `stream`.                          */
 int pxl_reproject_generic_last_tiles(int64_t* exact_tiles, int64_t* total_tiles, void* stream);

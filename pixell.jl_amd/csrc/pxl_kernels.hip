@@ -958,7 +958,7 @@ int pxl_reproject_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shap
     return rc;
 }
 
-// diagnostics of the tiled generic reprojection: how many 64 x 32 tiles of the last call took the exact path
+// diagnostics of the tiled generic reprojection: how many 128 x 32 tiles of the last call took the exact path
 static unsigned int* g_exact_tiles[64] = {};
 static int64_t g_generic_tiles[64] = {};
 static unsigned int* exact_tiles_counter(int* dev_out) {
@@ -1004,8 +1004,8 @@ int pxl_reproject_generic_bilinear_f64(const pxl_car_wcs* wcs_in, int proj_in, c
     if (proj_in == PXL_PROJ_TAN) p.in_tan = tan_setup(*wcs_in);
     else p.in_car = sky2pix_setup(*wcs_in, p.nx, p.ny, 1, PXL_FORM_DIV);
     // PXL_GENERIC_EXACT=1: per-pixel evaluation of the coordinates (the definition; cross-check and fallback of the
-    // tiled kernel, which interpolates them per 64 x 32 tile within PXL_TILED_TOL pixel)
-    const int64_t gx = (p.nxo + 63) / 64, gy = (p.nyo + PXL_TH - 1) / PXL_TH;
+    // tiled kernel, which interpolates them per 128 x 32 tile within PXL_TILED_TOL pixel)
+    const int64_t gx = (p.nxo + PXL_TW - 1) / PXL_TW, gy = (p.nyo + PXL_TH - 1) / PXL_TH;
     if (env_int("PXL_GENERIC_EXACT", 0) || gy > 65535) {
         hipLaunchKernelGGL(k_reproject_generic, dim3(stream_grid(p.nxo * p.nyo, 256)), dim3(256), 0, (hipStream_t)stream, p);
         return check_launch("k_reproject_generic");

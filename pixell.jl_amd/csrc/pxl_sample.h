@@ -67,10 +67,13 @@ __global__ __launch_bounds__(256) void k_reproject_generic(GenericParams p) {
 
 // ---- the same operator with the coordinate map interpolated per output tile (what python-pixell does for non-
 // separable reprojections, and the only way off the transcendental roof: ~10 FP64 libm calls per pixel above).
-// Tile = 64 x 32 output pixels.  The exact (x, y) of the reference's
-// evaluators is computed on a 6 x 6 lattice of the tile (42 evaluations per 2048 pixels with the check points) and
-// every pixel takes the tensor-product Lagrange interpolant of degree 5 x 5 (error ~ h^6 f^(6) / 6!: 1e-14 pixel at
-// 0.5 arcmin, below the rounding noise of the exact evaluation).  The interpolant is CHECKED per tile against exact evaluations at six off-lattice points: if either
+// Tile = 128 x 32 output pixels.  The exact (x, y) of the reference's
+// evaluators is computed on a 7 x 6 lattice of the tile (54 evaluations per 4096 pixels with the check points) and
+// every pixel takes the tensor-product Lagrange interpolant of degree 6 x 5 (truncation error ~1e-13 pixel at
+// 0.5 arcmin, below the rounding noise of the exact evaluation; 64-wide tiles with 6 x 6 nodes cost twice the lattice
+// work per pixel: 1.95 vs 1.75 ms on the 16-patch mosaic, and 128-wide tiles with only 6 nodes across fail the check
+// on a quarter of the tiles of a 34-degree patch).  The interpolant is CHECKED per tile against exact evaluations at
+// twelve off-lattice points: if either
 // coordinate is off by more than PXL_TILED_TOL pixel anywhere, or a lattice point is non-finite or behind the
 // tangent plane (the rewind jump of a periodic source and the Gnomonic horizon land here), the whole tile takes the
 // exact per-pixel path -- so the result differs from k_reproject_generic by at most PXL_TILED_TOL pixel in the
@@ -79,9 +82,17 @@ __global__ __launch_bounds__(256) void k_reproject_generic(GenericParams p) {
 // 1e-10 pixel: the per-pixel evaluation itself carries ~1e-11 pixel of libm rounding noise at x ~ 2e4 (ulp 3.6e-12,
 // a few ulp through atan2 / asin / division by the pixel size), so a tighter check fails on noise, not on the interpolant
 #define PXL_TILED_TOL 1e-10
-#define PXL_TNX 6
+#ifndef PXL_TNX
+#define PXL_TNX 7          // lattice nodes along a tile's width (degree 6)
+#endif
 #define PXL_TNY 6
-#define PXL_TH 32          // tile height (output rows); width is one wave = 64 columns
+#define PXL_TCHK0 (PXL_TNX * PXL_TNY <= 40 ? 40 : 48)     // first of the check lanes of a tile's wave
+#define PXL_TNCHK 12                                       // check points per tile (lanes PXL_TCHK0 ... + 11)
+#define PXL_TH 32          // tile height (output rows)
+#ifndef PXL_TW
+#define PXL_TW 128         // tile width (output columns): 64 or 128 (one or two waves side by side in the 256-thread block)
+#endif
+#define PXL_TROWS (256 / PXL_TW)        // output rows a block covers at once
 // Lagrange basis on the N equispaced nodes 0, h, ..., (N-1) h.  The denominators prod_{c != a} (a - c) h are
 // constants (+-120, 24, 12 x h^5 for N = 6; 24, 6, 4 x h^4 for N = 5): no division in the kernel.
 template <int N>
@@ -103,14 +114,14 @@ __device__ inline void lagrange_weights(double u, double h, double* w) {
         w[a] = num * (rh / (double)k);
     }
 }
-// Two launches.  k_generic_lattice: every tile's 30 lattice points + 6 check points, all tiles in parallel (one wave
+// Three launches.  k_generic_lattice: every tile's 42 lattice points + 12 check points, all tiles in parallel (one wave
 // per tile; the ~10 libm calls per point are the expensive part and no pixel waits behind them); per tile it leaves the
 // lattice coordinates and a flag (1 = the interpolant failed its check or a point is non-finite / not visible).
-// k_reproject_generic_tiled: one block per tile, 8 pixels per thread, no LDS and no barrier: the tile's lattice is
-// wave-uniform data.
-// The pixels of a tile sit at integer positions 0..63 x 0..15 of the lattice's coordinate system, the same in every
+// k_reproject_generic_tiled: one block per tile, 16 pixels per thread, no LDS and no barrier: the tile's lattice is
+// wave-uniform data.  k_reproject_generic_exact_tiles: the flagged tiles, per pixel.
+// The pixels of a tile sit at integer positions 0..127 x 0..31 of the lattice's coordinate system, the same in every
 // tile: their Lagrange weights are compile-time tables.
-struct TileWeights { double wx[64][PXL_TNX]; double wy[PXL_TH][PXL_TNY]; };
+struct TileWeights { double wx[PXL_TW][PXL_TNX]; double wy[PXL_TH][PXL_TNY]; };
 constexpr double lag_w(int n, double h, double u, int a) {
     double num = 1.0, den = 1.0;
     for (int c = 0; c < n; ++c)
@@ -119,8 +130,8 @@ constexpr double lag_w(int n, double h, double u, int a) {
 }
 constexpr TileWeights make_tile_weights() {
     TileWeights t{};
-    for (int u = 0; u < 64; ++u)
-        for (int a = 0; a < PXL_TNX; ++a) t.wx[u][a] = lag_w(PXL_TNX, 63.0 / (PXL_TNX - 1), (double)u, a);
+    for (int u = 0; u < PXL_TW; ++u)
+        for (int a = 0; a < PXL_TNX; ++a) t.wx[u][a] = lag_w(PXL_TNX, (PXL_TW - 1.0) / (PXL_TNX - 1), (double)u, a);
     for (int v = 0; v < PXL_TH; ++v)
         for (int b = 0; b < PXL_TNY; ++b) t.wy[v][b] = lag_w(PXL_TNY, (PXL_TH - 1.0) / (PXL_TNY - 1), (double)v, b);
     return t;
@@ -134,8 +145,8 @@ __global__ __launch_bounds__(256) void k_generic_lattice(GenericParams p, int64_
     const int w = threadIdx.x >> 6, k = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * 4 + w;
     const bool live = tile < ntiles;
-    const int64_t ti0 = live ? (tile % ntx) * 64 : 0, tj0 = live ? (tile / ntx) * PXL_TH : 0;
-    const double hx = 63.0 / (PXL_TNX - 1), hy = (PXL_TH - 1.0) / (PXL_TNY - 1);
+    const int64_t ti0 = live ? (tile % ntx) * PXL_TW : 0, tj0 = live ? (tile / ntx) * PXL_TH : 0;
+    const double hx = (PXL_TW - 1.0) / (PXL_TNX - 1), hy = (PXL_TH - 1.0) / (PXL_TNY - 1);
     if (k == 0) bad[w] = 0;
     __syncthreads();
     double ex = 0.0, ey = 0.0, cu = 0.0, cv = 0.0;
@@ -147,10 +158,17 @@ __global__ __launch_bounds__(256) void k_generic_lattice(GenericParams p, int64_
         lx[w][k] = ex; ly[w][k] = ey;
         lat[tile * (PXL_TNX * PXL_TNY) + k] = make_double2(ex, ey);
         if (!vis || !isfinite(ex) || !isfinite(ey)) bad[w] = 1;
-    } else if (live && k >= 40 && k < 46) {
-        const double us[6] = {6.3, 31.5, 56.7, 18.9, 44.1, 59.85};
-        const double vs[6] = {0.12 * PXL_TH, 0.47 * PXL_TH, 0.82 * PXL_TH, 0.70 * PXL_TH, 0.23 * PXL_TH, 0.94 * (PXL_TH - 1)};
-        cu = us[k - 40]; cv = vs[k - 40];
+    } else if (live && k >= PXL_TCHK0 && k < PXL_TCHK0 + PXL_TNCHK) {
+        // off-lattice check points, spread over the tile (fractions of its extent; none coincides with a node)
+        const double uf[12] = {0.10, 0.50, 0.90, 0.30, 0.70, 0.95, 0.04, 0.21, 0.41, 0.59, 0.79, 0.985};
+        const double vf[12] = {0.12, 0.47, 0.82, 0.70, 0.23, 0.94, 0.55, 0.97, 0.05, 0.88, 0.35, 0.63};
+        const double us[12] = {uf[0] * (PXL_TW - 1), uf[1] * (PXL_TW - 1), uf[2] * (PXL_TW - 1), uf[3] * (PXL_TW - 1), uf[4] * (PXL_TW - 1),
+                               uf[5] * (PXL_TW - 1), uf[6] * (PXL_TW - 1), uf[7] * (PXL_TW - 1), uf[8] * (PXL_TW - 1), uf[9] * (PXL_TW - 1),
+                               uf[10] * (PXL_TW - 1), uf[11] * (PXL_TW - 1)};
+        const double vs[12] = {vf[0] * (PXL_TH - 1), vf[1] * (PXL_TH - 1), vf[2] * (PXL_TH - 1), vf[3] * (PXL_TH - 1), vf[4] * (PXL_TH - 1),
+                               vf[5] * (PXL_TH - 1), vf[6] * (PXL_TH - 1), vf[7] * (PXL_TH - 1), vf[8] * (PXL_TH - 1), vf[9] * (PXL_TH - 1),
+                               vf[10] * (PXL_TH - 1), vf[11] * (PXL_TH - 1)};
+        cu = us[k - PXL_TCHK0]; cv = vs[k - PXL_TCHK0];
         bool vis;
         generic_coords(p, (double)(ti0 + 1) + cu, (double)(tj0 + 1) + cv, &ex, &ey, &vis);
         is_check = true;
@@ -181,10 +199,10 @@ __global__ __launch_bounds__(256) void k_generic_lattice(GenericParams p, int64_
 __global__ __launch_bounds__(256) void k_reproject_generic_exact_tiles(GenericParams p, const int32_t* __restrict__ flag) {
     const int64_t tile = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
     if (!flag[tile]) return;
-    const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63), jr0 = (int64_t)blockIdx.y * PXL_TH + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * PXL_TW + (threadIdx.x & (PXL_TW - 1)), jr0 = (int64_t)blockIdx.y * PXL_TH + threadIdx.x / PXL_TW;
     if (i >= p.nxo) return;
-    for (int q = 0; q < PXL_TH / 4; ++q) {
-        const int64_t jr = jr0 + 4 * q;
+    for (int q = 0; q < PXL_TH / PXL_TROWS; ++q) {
+        const int64_t jr = jr0 + PXL_TROWS * q;
         if (jr < p.nyo) {
             double x, y; bool visible;
             generic_coords(p, (double)(i + 1), (double)(jr + 1), &x, &y, &visible);
@@ -195,11 +213,11 @@ __global__ __launch_bounds__(256) void k_reproject_generic_exact_tiles(GenericPa
 __global__ __launch_bounds__(256) void k_reproject_generic_tiled(GenericParams p, const double2* __restrict__ lat,
                                                                  const int32_t* __restrict__ flag) {
     const int64_t tile = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-    const int64_t ti0 = (int64_t)blockIdx.x * 64, tj0 = (int64_t)blockIdx.y * PXL_TH;   // 0-based tile origin
+    const int64_t ti0 = (int64_t)blockIdx.x * PXL_TW, tj0 = (int64_t)blockIdx.y * PXL_TH;   // 0-based tile origin
     const int tid = threadIdx.x;
     // ry through readfirstlane: the row weights c_tile_weights.wy[ry + 4q] are then wave-uniform SCALAR loads; as plain
     // tid >> 6 they were three 16-byte VECTOR loads per pixel, a dependent L1 round trip in front of every pixel's taps
-    const int cx = tid & 63, ry = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cx = tid & (PXL_TW - 1), ry = __builtin_amdgcn_readfirstlane(tid / PXL_TW);
     const int64_t i = ti0 + cx;
     if (i >= p.nxo) return;
     if (flag[tile]) return;                      // k_reproject_generic_exact_tiles does this tile
@@ -217,8 +235,8 @@ __global__ __launch_bounds__(256) void k_reproject_generic_tiled(GenericParams p
         colx[b] = sx; coly[b] = sy;
     }
 #pragma unroll
-    for (int q = 0; q < PXL_TH / 4; ++q) {
-        const int r = ry + 4 * q;
+    for (int q = 0; q < PXL_TH / PXL_TROWS; ++q) {
+        const int r = ry + PXL_TROWS * q;
         const int64_t jr = tj0 + r;
         if (jr < p.nyo) {
             double x = 0.0, y = 0.0;

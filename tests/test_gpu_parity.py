@@ -533,7 +533,7 @@ def test_generic_reproject_car_tan(pj, O, dev, literals):
         assert np.isfinite(got).all()
         assert np.abs(got - exp).max() < 1e-9, (p_in, p_out, np.abs(got - exp).max())
         assert np.abs(exp).max() > 0.1                      # the maps overlap: this is not a comparison of zeros
-    # the tiled kernel (coordinates interpolated per 64 x 32 tile, checked to 1e-10 pixel) against the per-pixel one
+    # the tiled kernel (coordinates interpolated per 128 x 32 tile, checked to 1e-10 pixel) against the per-pixel one
     # (PXL_GENERIC_EXACT=1) and the oracle: a periodic full-sky CAR source seen from a TAN patch that straddles the
     # RA = 180 deg seam (tiles across the rewind jump must fall back to exact evaluation), at 0.5 and at 20 arcmin
     # (coarse pixels: the interpolant fails its check everywhere and every tile takes the exact path)
