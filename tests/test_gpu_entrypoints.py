@@ -17,9 +17,11 @@ def test_smoke_entry():
     g.smoke()
 
 
-@pytest.mark.parametrize("workload", ["cfg2", "cfg5"])
+@pytest.mark.parametrize("workload", ["cfg2", "cfg5", "cfg5:pairs"])
 def test_bench_contract(workload):
     env = dict(os.environ, PXL_BENCH_POINTS="2e6")
+    if workload.endswith(":pairs"):          # the sampler the default 1e9-point run takes (row-pair copy rebuilt inside every step)
+        workload, env["PXL_BENCH_SAMPLER"] = "cfg5", "pairs"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "3",
                         "--warmup", "1", "--check"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -32,6 +34,8 @@ def test_bench_contract(workload):
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    if env.get("PXL_BENCH_SAMPLER") == "pairs":
+        assert rf["kernel"] == "k_sample_pairs" and "row-pair" in d["config"]["sampler"]
     if workload == "cfg2":
         assert d["check"]["bit_identical"] and d["check"]["max_abs_err"] == 0.0
         cb = d["cpu_baseline"]
