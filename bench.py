@@ -200,7 +200,7 @@ def main():
                     help="(default) carve the source and destination maps out of ONE allocation, destination above the source: "
                          "DecStripReprojector.alloc_pair, a fixed policy any caller can use, nothing probed.  Where the destination "
                          "lands physically moves the kernel by up to 10 %% (DESIGN 9 item 6): this arrangement gave the fast case in "
-                         "20 of 22 processes on 8 boxes, two separate allocations in about half")
+                         "20 of 24 processes on 9 boxes, two separate allocations in about half")
     ap.add_argument("--two-allocations", dest="arena", action="store_false",
                     help="allocate the source and the destination separately (round 1's and early round 2's default)")
     ap.add_argument("--keep-placement", default="first", choices=["first", "best"],
