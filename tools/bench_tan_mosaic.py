@@ -47,4 +47,5 @@ for name, env in (("tiled", None), ("per_pixel", "1")):
                       "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
                                    "frac": round(alg / ms / 1e6 / 8000, 4), "algorithmic_bytes": alg}}), flush=True)
 worst = max(float((a.data - b.data).abs().max()) for a, b in zip(rows["tiled"], rows["per_pixel"]))
+print(json.dumps({"tiled_output_bits_checksum": int(sum(int(o.data.view(torch.int64).sum().item()) for o in rows["tiled"]) & 0xffffffffffff)}))
 print(json.dumps({"max_abs_diff_tiled_vs_per_pixel": worst, "note": "N(0,1) white-noise map: a sampling-position error of e pixel moves a value by ~2e"}))
