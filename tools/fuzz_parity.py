@@ -350,8 +350,66 @@ def fuzz_sample(rng):
     return "sample_f32" if f32 else "sample_f64"
 
 
-KINDS = {"reproject": (fuzz_reproject, 0.55), "elementwise": (fuzz_elementwise, 0.15), "unwind": (fuzz_unwind, 0.1),
-         "posmap": (fuzz_posmap, 0.05), "sample": (fuzz_sample, 0.15)}
+def fuzz_generic(rng):
+    """CAR <-> Gnomonic reprojection (tolerance-checked: FP64 transcendentals): the tiled kernel against the oracle and
+    against the per-pixel kernel, random resolutions, patch sizes and centres (seam, high declinations, patches partly
+    off the source, the Gnomonic horizon), one or two components."""
+    res = float(rng.choice([60.0, 30.0, 20.0, 10.0, 4.0])) / 60.0                  # degrees per pixel
+    ra0 = float(rng.choice([rng.uniform(-180, 180), 179.95, -179.9, 0.0]))
+    dec0 = float(rng.choice([rng.uniform(-60, 60), rng.uniform(-88, 88), 0.0]))
+
+    def tan_geometry(scale=1.0):
+        r = res * scale * rng.uniform(0.7, 1.4)
+        nx, ny = int(rng.integers(20, 420)), int(rng.integers(20, 330))
+        crpix = (nx / 2 + rng.uniform(-0.3, 0.3) * nx, ny / 2 + rng.uniform(-0.3, 0.3) * ny)
+        sx = -1.0 if rng.random() < 0.7 else 1.0
+        return (nx, ny), pj.Gnomonic((sx * r, r * rng.uniform(0.9, 1.1)), crpix, (ra0 + rng.uniform(-3, 3) * res, dec0 + rng.uniform(-3, 3) * res))
+
+    def car_geometry():
+        if res >= 10.0 / 60.0 and rng.random() < 0.6:                               # periodic full sky
+            return pj.fullsky_geometry(math.radians(res))
+        half = res * rng.uniform(60, 250)
+        d0 = max(-89.0, min(89.0, dec0))
+        box = [[math.radians(ra0 + half), math.radians(ra0 - half)], [math.radians(max(-89.5, d0 - half * 0.7)), math.radians(min(89.5, d0 + half * 0.7))]]
+        return pj.geometry(box, math.radians(res))
+
+    direction = rng.choice(["car->tan", "car->tan", "car->tan", "tan->car", "tan->tan"])
+    if direction == "car->tan":
+        (s_in, w_in), p_in = car_geometry(), 0
+        (s_out, w_out), p_out = tan_geometry(), 1
+    elif direction == "tan->car":
+        (s_in, w_in), p_in = tan_geometry(), 1
+        (s_out, w_out), p_out = car_geometry(), 0
+        if s_out[0] * s_out[1] > 400000:
+            return "skipped-size"
+    else:
+        (s_in, w_in), p_in = tan_geometry(), 1
+        (s_out, w_out), p_out = tan_geometry(rng.uniform(0.5, 2.0)), 1
+    s_in = tuple(int(v) for v in s_in[:2]); s_out = tuple(int(v) for v in s_out[:2])
+    if s_in[0] * s_in[1] > 3000000 or s_out[0] * s_out[1] > 400000 or min(s_in + s_out) < 2:
+        return "skipped-size"
+    nc = int(rng.choice([1, 1, 2]))
+    yy, xx = np.meshgrid(np.arange(s_in[1]), np.arange(s_in[0]), indexing="ij")
+    src = np.stack([np.sin(0.011 * (c + 1) * xx + 0.3) * np.cos(0.013 * yy) + 0.001 * c * xx for c in range(nc)])
+    params = dict(direction=direction, s_in=s_in, w_in=w_in, s_out=s_out, w_out=w_out, nc=nc)
+    exp = O.reproject_generic(w_in, p_in, (s_in[0], s_in[1], nc), src, w_out, p_out, s_out)
+    m = pj.Enmap(to_dev(src if nc > 1 else src[0]), w_in)
+    tiled = pj.reproject(m, s_out, w_out).data.cpu().numpy().reshape(nc, s_out[1], s_out[0])
+    os.environ["PXL_GENERIC_EXACT"] = "1"
+    try:
+        exact = pj.reproject(m, s_out, w_out).data.cpu().numpy().reshape(nc, s_out[1], s_out[0])
+    finally:
+        del os.environ["PXL_GENERIC_EXACT"]
+    assert np.array_equal(np.isnan(exact), np.isnan(exp)) and np.array_equal(np.isnan(tiled), np.isnan(exp)), ("generic: NaN pattern", params)
+    e1 = float(np.nanmax(np.abs(exact - exp))) if exp.size else 0.0
+    e2 = float(np.nanmax(np.abs(tiled - exp))) if exp.size else 0.0
+    e3 = float(np.nanmax(np.abs(tiled - exact))) if exp.size else 0.0
+    assert e1 < 1e-9 and e2 < 1e-9 and e3 < 2e-10, ("generic: tolerance", (e1, e2, e3), params)
+    return direction
+
+
+KINDS = {"reproject": (fuzz_reproject, 0.5), "elementwise": (fuzz_elementwise, 0.15), "unwind": (fuzz_unwind, 0.1),
+         "posmap": (fuzz_posmap, 0.05), "sample": (fuzz_sample, 0.15), "generic": (fuzz_generic, 0.05)}
 
 
 def main():
