@@ -350,6 +350,36 @@ def fuzz_sample(rng):
     return "sample_f32" if f32 else "sample_f64"
 
 
+def fuzz_maps(rng):
+    """pixareamap! on random CAR geometries (device sin vs the host's: a few ulp of sin(dec) ~ 1, scaled by the RA pixel
+    width; constant along RA, every row) and the Gnomonic posmap against the oracle's evaluators (libm-level tolerance)."""
+    if rng.random() < 0.6:
+        shape, wcs = rand_geometry(rng, cls=rng.choice(["tiny", "small", "medium", "wide", "tall"]))
+        if shape[0] * shape[1] > 6e6:
+            return "skipped-size"
+        pm = pj.pixareamap(shape, wcs, device=DEV)
+        col = pm.data[:, 0].cpu().numpy()
+        ref = O.pixarea_rows(wcs, shape[1])
+        tol = 8 * np.finfo(float).eps * abs(wcs.cdelt[0] * wcs.unit)
+        assert np.abs(col - ref).max() <= tol, ("pixareamap", shape, wcs, float(np.abs(col - ref).max()), tol)
+        assert bool((pm.data == pm.data[:, :1]).all()), ("pixareamap not constant along RA", shape, wcs)
+        return "pixareamap"
+    res = 10 ** rng.uniform(-2.5, 0.0)
+    nx, ny = int(rng.integers(1, 700)), int(rng.integers(1, 500))
+    if res * max(nx, ny) > 40.0:          # patches beyond ~40 degrees approach the horizon, where asin / atan2 amplify an ulp
+        res = 40.0 / max(nx, ny)          # of difference between the device's and the host's libm beyond any fixed bound
+    wcs = pj.Gnomonic((-res if rng.random() < 0.7 else res, res * rng.uniform(0.9, 1.1)),
+                      (nx / 2 + rng.uniform(-40, 40), ny / 2 + rng.uniform(-40, 40)), (rng.uniform(-180, 180), rng.uniform(-89, 89)))
+    ra, dec = pj.posmap((nx, ny), wcs, device=DEV)
+    jj, ii = np.meshgrid(np.arange(1, ny + 1, dtype=float), np.arange(1, nx + 1, dtype=float), indexing="ij")
+    era, edec = O.pix2sky_tan(wcs, ii.ravel(), jj.ravel())
+    gra, gdec = ra.data.cpu().numpy().ravel(), dec.data.cpu().numpy().ravel()
+    dra = np.abs(np.angle(np.exp(1j * (gra - era))))            # RA compared on the circle
+    assert np.nanmax(dra) < 1e-11 and np.nanmax(np.abs(gdec - edec)) < 1e-11, ("tan posmap", (nx, ny), wcs, float(np.nanmax(dra)), float(np.nanmax(np.abs(gdec - edec))))
+    assert np.array_equal(np.isnan(gra), np.isnan(era))
+    return "tan_posmap"
+
+
 def fuzz_generic(rng):
     """CAR <-> Gnomonic reprojection (tolerance-checked: FP64 transcendentals): the tiled kernel against the oracle and
     against the per-pixel kernel, random resolutions, patch sizes and centres (seam, high declinations, patches partly
@@ -409,7 +439,7 @@ def fuzz_generic(rng):
 
 
 KINDS = {"reproject": (fuzz_reproject, 0.5), "elementwise": (fuzz_elementwise, 0.15), "unwind": (fuzz_unwind, 0.1),
-         "posmap": (fuzz_posmap, 0.05), "sample": (fuzz_sample, 0.15), "generic": (fuzz_generic, 0.05)}
+         "posmap": (fuzz_posmap, 0.05), "sample": (fuzz_sample, 0.15), "generic": (fuzz_generic, 0.05), "maps": (fuzz_maps, 0.03)}
 
 
 def main():
