@@ -2,11 +2,13 @@
 """bench.py -- headline benchmark: Float64 CAR bilinear reprojection throughput (Mpix/s) and fraction of
 the MI355X HBM roofline, at 1/2/4/8 GPUs of one node (strong scaling, dec-strip sharding, RCCL halo).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg4x2|cfg3|cfg2|cfg5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg4x2|cfg3|cfg3s|cfg2|cfg5]
 
-For N > 1 launch one rank per GPU:
+For N > 1 there is one rank per GPU.  Either launch them yourself,
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+or call `python bench.py --gpus N ...` from a bare shell: with no WORLD_SIZE in the environment the process starts
+exactly that command as a child (before it has touched the GPU), relays the one JSON line and exits with its code.
 
 A "step" is one pass of the hot path over the whole synthetic map (inputs resident in HBM): halo exchange
 (N > 1) + coordinate-table build + reprojection of every component.  Rank 0 prints ONE JSON line.
@@ -16,13 +18,22 @@ Workloads (BASELINE.json configs; natural Clenshaw-Curtis shapes, ny = nx/2 + 1)
                     This is the configuration north_star quotes the metric on ("full-sky 0.5-arcmin CAR
                     bilinear reprojection", ">= 6x strong scaling to 8 GPUs"); it fits one GPU (44.8 GB).
     cfg3: (21600, 10801) -> (43200, 21601) 2x refinement, 10 B per output pixel.
+    cfg3s: (21600, 10801) -> same shape, half-pixel-shifted WCS (second workload), 16 B.
     cfg2: (4096, 2049) -> (8192, 4097) (Infinity-Cache resident; informational).
     cfg5: 1e9 scattered (ra, dec) points sampled from a (43200, 21601) map replicated per GPU.
+
+The default run (N = 1, workload cfg4) appends, after the headline and outside its timed region, a "configs" block
+with the other BASELINE configs measured in the same process (cfg2, cfg3, cfg3s, cfg5 at 1e9 points: ms per step,
+kernel average, roofline fraction, oracle check), an "evaluators" block (posmap, pix2sky!, sky2pix! on the GPU) and
+the CPU oracle's rates for the functions the reference has (cpu_baseline.posmap / .pix2sky / .sky2pix).
+--no-configs skips all of that.
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -61,6 +72,11 @@ def workload_geometry(name):
         shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 21600)
         shape_out, wcs_out = pj.fullsky_geometry(2 * math.pi / 43200)
         desc = "cfg3: 21600x10801 I-only Float64 full-sky CAR -> 2x-refined 43200x21601"
+    elif name == "cfg3s":       # SURVEY 8(d) config 3, second workload: same resolution, crval shifted by half a pixel in both axes
+        shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 21600)
+        shape_out = shape_in[:2]
+        wcs_out = pj.CarClenshawCurtis(wcs_in.cdelt, (wcs_in.crpix[0] + 0.5, wcs_in.crpix[1] + 0.5), wcs_in.crval)
+        desc = "cfg3s: 21600x10801 I-only Float64 full-sky CAR -> same shape, half-pixel-shifted WCS (1 arcmin)"
     elif name == "cfg2":
         shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 4096)
         shape_out, wcs_out = pj.fullsky_geometry(2 * math.pi / 8192)
@@ -214,7 +230,12 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path); gloo = host-staged halo, only for rehearsing "
                          "the N-rank flow on a box with fewer GPUs than ranks (with PXL_BENCH_SHARE_GPU=1)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the side measurements the default run appends after the headline (configs / evaluators blocks "
+                         "and the evaluators' CPU baselines)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     # stdout carries exactly one JSON line: libraries (RCCL prints a version banner, gloo its connection notes) write
     # to file descriptor 1 behind Python's back, so everything else is sent to stderr from here on
@@ -226,8 +247,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         sys.exit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: there is no CPU fallback for the product path")
@@ -250,6 +269,8 @@ def main():
         result = bench_scattered(args, rank, world, dev)
     else:
         result = bench_reproject(args, rank, world, dev)
+    if world == 1 and args.workload == "cfg4" and not args.no_configs:
+        side_measurements(args, dev, result)
     if rank == 0:
         json_out.write(json.dumps(result) + "\n")
         json_out.flush()
@@ -258,6 +279,28 @@ def main():
         dist.destroy_process_group()
     if args.backend == "nccl" and _CTRL is not None and args.halo != "gloo":
         sys.exit(4)                                      # cannot happen (gloo is opt-in); belt and braces
+
+
+def self_launch(ngpus, argv):
+    """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE): start the N ranks as a CHILD job -- this process has
+    not touched the GPU and never does; nothing is re-exec'ed -- relay the ranks' one JSON line to stdout, everything
+    else to stderr, and return the job's exit code."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("bench.py: no WORLD_SIZE in the environment; starting %d ranks: %s" % (ngpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in proc.stdout:
+        if line.lstrip().startswith("{"):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    return proc.wait()
 
 
 _CTRL = None        # gloo control group, set when the RCCL transport failed and the run fell back to gloo
@@ -529,13 +572,13 @@ def bench_scattered(args, rank, world, dev):
         mode = "pairs" if n >= 3e8 else "direct"
     pairs = torch.empty(lib.pxl_sample_pairs_elems(shp, ny), dtype=torch.float64, device=dev) if mode == "pairs" else None
 
-    def step(k, ev=None):
+    def step(k, ev=None, how=mode, rebuild=True):
         s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        if mode == "pairs":
+        if how == "pairs" and rebuild:
             pj._lib.check(lib.pxl_sample_build_pairs_f64(shp, C.c_void_p(m.data.data_ptr()), ny, C.c_void_p(pairs.data_ptr()), s))
         if ev:
             ev[0].record()
-        if mode == "pairs":
+        if how == "pairs":
             pj._lib.check(lib.pxl_sample_car_bilinear_pairs_f64(C.byref(wref), shp, C.c_void_p(pairs.data_ptr()), 0, ny, n,
                                                                 C.c_void_p(sky.data_ptr()), C.c_void_p(out.data_ptr()), s))
         else:
@@ -553,7 +596,7 @@ def bench_scattered(args, rank, world, dev):
     k_avg_ms = sum(kms) / len(kms)
     alg = 56.0 * n                                                  # 16 coords + 4x8 taps + 8 out
     achieved = alg / (k_avg_ms * 1e-3) / 1e9
-    return {
+    result = {
         "metric": "Mpts/s scattered sky2pix + bilinear sample (Float64)",
         "value": round(npts_total * args.steps / dt / 1e6, 1), "unit": "Mpts/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -567,6 +610,176 @@ def bench_scattered(args, rank, world, dev):
                      "algorithmic_bytes_per_launch": alg, "sector_granular_bytes_per_launch": 152.0 * n,
                      "kernel_ms_avg": round(k_avg_ms, 4)},
     }
+    # the output of the last timed step against the oracle on a seeded subset of this rank's points (outside the timed region)
+    result["check"] = scattered_check(m, wcs, shape, sky, out, world, dev)
+    if world == 1 and mode == "pairs":
+        # the two other ways a caller can run the same batch (not the headline; HIP events around each step):
+        # the map does NOT change between batches -- the row-pair copy is built once and reused -- and the direct sampler
+        def timed(how, rebuild, steps):
+            step(0, None, how, rebuild)
+            torch.cuda.synchronize(dev)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for k in range(steps):
+                step(k, None, how, rebuild)
+            b.record()
+            torch.cuda.synchronize(dev)
+            return round(a.elapsed_time(b) / steps, 4)
+        fixed_ms = timed("pairs", False, max(3, args.steps))
+        fixed_chk = scattered_check(m, wcs, shape, sky, out, world, dev)
+        direct_ms = timed("direct", False, max(2, args.steps // 3))
+        direct_chk = scattered_check(m, wcs, shape, sky, out, world, dev)
+        result["variants"] = {
+            "map_changes_every_step": {"ms_per_step": result["ms_per_step"], "note": "the headline: the row-pair copy is rebuilt inside every step"},
+            "map_fixed": {"ms_per_step": fixed_ms, "check": fixed_chk,
+                          "note": "row-pair copy built once (pj.SamplePairs) and reused: what a caller sampling one map with many batches pays"},
+            "direct": {"ms_per_step": direct_ms, "check": direct_chk, "note": "pxl_sample_car_bilinear_f64 straight from the Julia-layout map (no copy)"}}
+    return result
+
+
+def scattered_check(m, wcs, shape, sky, out, world, dev, npick=4096):
+    """A seeded subset of this rank's points through the oracle's sampler (same map bytes, same coordinates)."""
+    import numpy as np
+    from oracle import oracle as O
+    n = sky.shape[0]
+    g = torch.Generator(device="cpu").manual_seed(7)
+    idx = torch.randint(0, n, (min(npick, n),), generator=g).to(dev)
+    pts = sky[idx].cpu().numpy()
+    got = out[0, idx].cpu().numpy()
+    exp = O.sample_bilinear(wcs, (shape[0], shape[1], 1), m.data.cpu().numpy()[None], pts)[0]
+    chk = {"points_checked": int(idx.numel()), "max_abs_err": float(np.abs(got - exp).max()),
+           "bit_identical": bool(np.array_equal(got.view(np.int64), exp.view(np.int64)))}
+    if world > 1:
+        t = torch.tensor([chk["max_abs_err"], 0.0 if chk["bit_identical"] else 1.0], dtype=torch.float64,
+                         device="cpu" if _on_host() else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_CTRL)
+        chk.update({"max_abs_err": float(t[0]), "bit_identical": bool(t[1] == 0.0), "ranks_checked": world})
+    return chk
+
+
+def side_measurements(args, dev, result):
+    """After the headline, outside its timed region (N = 1, default workload): the other BASELINE configs, the
+    evaluators the reference has, and the CPU oracle's rates for them -- so that one driver-observed line carries
+    what used to live only in builder-kept files under profiles/."""
+    cfgs = {}
+    for name in ("cfg2", "cfg3", "cfg3s"):
+        a = argparse.Namespace(**vars(args))
+        a.workload, a.steps, a.warmup, a.sustain_seconds, a.no_cpu_baseline, a.placements = name, 10, 2, 0.0, True, 1
+        torch.cuda.empty_cache()
+        r = bench_reproject(a, 0, 1, dev)
+        cfgs[name] = {"workload": r["config"]["workload"], "Mpix_s": r["value"], "ms_per_step": r["ms_per_step"],
+                      "kernel_ms_avg": r["roofline"]["kernel_ms_avg"], "frac": r["roofline"]["frac"],
+                      "achieved_GBs": r["roofline"]["achieved"], "bytes_per_output_value": r["config"]["bytes_per_output_value"],
+                      "traffic": r["roofline"]["traffic"], "steps": a.steps, "check": r["check"]}
+        if name == "cfg2":
+            cfgs[name]["note"] = "268 MB of output: Infinity-Cache resident, not roofline evidence (SURVEY 8(d))"
+    a = argparse.Namespace(**vars(args))
+    a.workload, a.steps, a.warmup = "cfg5", 6, 2
+    torch.cuda.empty_cache()
+    r = bench_scattered(a, 0, 1, dev)
+    cfgs["cfg5"] = {"workload": r["config"]["workload"], "Mpts_s": r["value"], "ms_per_step": r["ms_per_step"],
+                    "kernel": r["roofline"]["kernel"], "kernel_ms_avg": r["roofline"]["kernel_ms_avg"], "frac": r["roofline"]["frac"],
+                    "steps": a.steps, "sampler": r["config"]["sampler"], "check": r["check"], "variants": r.get("variants")}
+    torch.cuda.empty_cache()
+    result["configs"] = cfgs
+    result["evaluators"] = gpu_evaluators(dev)
+    torch.cuda.empty_cache()
+    if "cpu_baseline" in result:
+        result["cpu_baseline"].update(cpu_baseline_evaluators())
+
+
+def _median_ms(fn, dev, reps=7):
+    fn()
+    torch.cuda.synchronize(dev)
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize(dev)
+        ts.append(a.elapsed_time(b))
+    return sorted(ts)[len(ts) // 2]
+
+
+def gpu_evaluators(dev):
+    """The reference's own batched functions on the 0.5-arcmin full-sky geometry: posmap (enmap_ops.jl:190-203), pix2sky!
+    and sky2pix! on 2xN batches (car_proj.jl:92-122, 165-200); HIP-event medians, bytes as in SURVEY 8(a)."""
+    shape, wcs = pj.fullsky_geometry(2 * math.pi / 43200)
+    g = (shape, wcs)
+    out = {}
+
+    def rec(name, ms, nbytes, units, unit, ref):
+        out[name] = {"ms": round(ms, 4), "GBs": round(nbytes / ms / 1e6, 1), "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                     unit: round(units / ms / 1e3, 1), "reference": ref}
+    npx = shape[0] * shape[1]
+    ra = torch.empty((shape[1], shape[0]), dtype=torch.float64, device=dev)
+    dec = torch.empty_like(ra)
+    lib = pj.load_library()
+    import ctypes as C
+    wref = wcs.to_struct()
+    sh2 = (C.c_int64 * 2)(shape[0], shape[1])
+
+    def posmap():
+        s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        pj._lib.check(lib.pxl_posmap_car_f64(C.byref(wref), sh2, 0, shape[1], C.c_void_p(ra.data_ptr()), C.c_void_p(dec.data_ptr()), 1, s))
+    rec("posmap", _median_ms(posmap, dev), 16.0 * npx, npx, "Mpix_s", "enmap_ops.jl:190-203 (safe=true), 43200x21601, write-only 16 B/pixel")
+    del ra, dec
+    n = 200_000_000
+    pix = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    pj.fill_random_(pix, 1, kind="uniform")
+    pix.mul_(float(shape[1]))
+    sky = torch.empty_like(pix)
+    rec("pix2sky!(safe=false)", _median_ms(lambda: pj.pix2sky_(g, pix, sky, safe=False), dev), 32.0 * n, n, "Mpts_s", "car_proj.jl:92-122, 2xN, 2e8 points")
+    back = torch.empty_like(pix)
+    rec("sky2pix!(safe=true)", _median_ms(lambda: pj.sky2pix_(g, sky, back, safe=True), dev), 32.0 * n, n, "Mpts_s", "car_proj.jl:165-200, 2xN, 2e8 points")
+    del back
+    nb = n // 2
+    rec("pix2sky!(safe=true)", _median_ms(lambda: pj.pix2sky_(g, pix[:nb], sky[:nb], safe=True), dev, reps=5), 32.0 * nb, nb, "Mpts_s",
+        "car_proj.jl:92-122 with unwind! (enmap_ops.jl:26-32), 2xN, 1e8 points")
+    return out
+
+
+def cpu_baseline_evaluators():
+    """The oracle's loops for the functions the reference DOES have (posmap: enmap_ops.jl:190-203; pix2sky! / sky2pix! on
+    2xN: car_proj.jl:92-122, 165-200, safe=true as the reference defaults), on bounded samples of the 0.5-arcmin geometry:
+    one core (the reference's execution model) and all host cores (OpenMP)."""
+    import numpy as np
+    from oracle import oracle as O
+    shape, wcs = pj.fullsky_geometry(2 * math.pi / 43200)
+    nx, ny = shape
+    cores = min(O.max_threads(), os.cpu_count() or 1)
+    res = {}
+
+    def timed(fn, threads):
+        O.set_threads(threads)
+        t0 = time.perf_counter()
+        fn()
+        dt = time.perf_counter() - t0
+        O.set_threads(1)
+        return dt
+    rows1 = 600
+    v1 = nx * rows1 / timed(lambda: O.posmap(wcs, shape, row0=ny // 2 - rows1 // 2, nrows=rows1), 1) / 1e6
+    rowsN = int(min(8000, max(rows1, 2.0 * v1 * 1e6 * cores * 0.5 / nx)))
+    vN = nx * rowsN / timed(lambda: O.posmap(wcs, shape, row0=ny // 2 - rowsN // 2, nrows=rowsN), cores) / 1e6
+    res["posmap"] = {"value": round(vN, 1), "value_1core": round(v1, 1), "unit": "Mpix/s", "cores": cores, "kind": "port",
+                     "sample": "oracle posmap (enmap_ops.jl:190-203, safe=true) of %d (all-core) / %d (1-core) centre rows x %d columns" % (rowsN, rows1, nx)}
+    rng = np.random.default_rng(1)
+    n1 = 10_000_000
+    nN = int(min(200_000_000, max(n1, n1 * cores // 4)))
+    pix = rng.random((nN, 2)) * ny
+    O.set_threads(cores)
+    sky_pts = O.pix2sky(wcs, pix, O.WRAP_NONE)
+    O.set_threads(1)
+    for name, arr, fn in (("pix2sky", pix, lambda a: O.pix2sky(wcs, a, O.WRAP_UNWIND)),
+                          ("sky2pix", sky_pts, lambda a: O.sky2pix(wcs, shape, a, safe=True))):
+        v1 = n1 / timed(lambda: fn(arr[:n1]), 1) / 1e6
+        vN = nN / timed(lambda: fn(arr), cores) / 1e6
+        res[name] = {"value": round(vN, 1), "value_1core": round(v1, 1), "unit": "Mpts/s", "cores": cores, "kind": "port",
+                     "sample": "oracle %s! on a 2xN batch (car_proj.jl:%s, safe=true) of %d (all-core) / %d (1-core) random points%s" % (
+                         name, "92-122 + unwind!, enmap_ops.jl:26-32" if name == "pix2sky" else "165-200", nN, n1,
+                         "; the unwrap recurrence is serial in the reference and stays serial here" if name == "pix2sky" else "")}
+    return res
 
 
 if __name__ == "__main__":

@@ -604,9 +604,11 @@ int pxl_reproject_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[
         int64_t s = (int64_t)span;
         return (s + 1) & ~(int64_t)1;
     };
-    // lane width: 2 pairs (256 columns per wave) by default; strong up-sampling (>= ~3x) is store-issue bound and
-    // gains 15 % from 512 columns per wave (measured on 10800 -> 43200)
-    int want = env_int("PXL_REPROJECT_PAIRS", sx <= 0.3 ? 4 : 2);
+    // lane width: 2 pairs (256 columns per wave) at equal resolution; up-sampling in RA takes 512 columns per wave
+    // (4 KB contiguous per store row, half the column-halo re-reads): +15 % at >= ~3x (10800 -> 43200) and, since the
+    // row loop keeps one interpolant per source row in registers, +2 % at 2x (round 3: 1.794 vs 1.830 ms on the
+    // 1' -> 0.5' map in a slow placement, 1.631 vs 1.638 ms in a fast one; profiles/r03_tune_cfg3_a.txt)
+    int want = env_int("PXL_REPROJECT_PAIRS", sx <= 0.55 ? 4 : 2);
     if (want != 1 && want != 2 && want != 4) want = 2;
     // LDS-DMA kernel: widest lane width whose slot fits
     pl->pairs_dma = want;

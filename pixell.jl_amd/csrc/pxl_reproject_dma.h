@@ -11,8 +11,13 @@
 // row (slot = t & (ns-1), t = +-row), and all bookkeeping is wave-uniform scalar arithmetic:
 //   treq        highest t requested so far
 //   need        t0 + 1, the farther of the two rows the current output row reads
-//   s_waitcnt vmcnt((treq - need) * NCH)   -- exactly the DMA instructions issued after row `need`'s
-// (stores also count in vmcnt, in issue order, so ignoring them only makes the wait stricter).
+//   vm_total    vector-memory instructions this wave has issued (DMAs + its own 16-byte stores)
+//   marks       lane s: vm_total right after the DMAs of the row in ring slot s
+//   s_waitcnt vmcnt(vm_total - marks[need])   -- exactly what was issued after row `need`'s DMAs: vmcnt retires in
+// issue order, stores included, so a wait that ignored the stores (round 2: vmcnt((treq - need) * NCH)) also waited
+// for the acknowledgement of the wave's own recent stores and cut the effective prefetch distance in half.
+// Each source row is read from LDS ONCE per tile: its horizontal interpolant at the lane's columns is kept in
+// registers and serves as `top` and as `bot` of every output row that touches it (bit-identical: same operations).
 // Tiles that are not monotone, or whose columns do not fit the slot, take the direct-tap fallback.
 //
 // RA seam: slot element k holds source column (cbase0 + k) mod nx, resolved in the per-lane source
@@ -40,6 +45,33 @@ __device__ __forceinline__ void wait_rows(int k) {
         case 5: wait_vm<5 * NCH>(); break;
         case 6: wait_vm<6 * NCH>(); break;
         default: wait_vm<7 * NCH>(); break;
+    }
+}
+
+// wait until at most k vector-memory instructions of this wave are outstanding (k rounded DOWN to an immediate the
+// switch carries: a stricter wait is always safe).  vmcnt is a 6-bit counter on gfx9 and retires in issue order,
+// loads and stores alike.
+__device__ __forceinline__ void wait_vm_upto(int k) {
+    // a hand-written comparison tree (the compiler turns a dense switch over immediates into a chain of flag tests)
+    if (k < 8) {
+        if (k < 4) {
+            if (k < 2) { if (k < 1) wait_vm<0>(); else wait_vm<1>(); }
+            else       { if (k < 3) wait_vm<2>(); else wait_vm<3>(); }
+        } else {
+            if (k < 6) { if (k < 5) wait_vm<4>(); else wait_vm<5>(); }
+            else       { if (k < 7) wait_vm<6>(); else wait_vm<7>(); }
+        }
+    } else if (k < 16) {
+        if (k < 12) {
+            if (k < 10) { if (k < 9) wait_vm<8>(); else wait_vm<9>(); }
+            else        { if (k < 11) wait_vm<10>(); else wait_vm<11>(); }
+        } else {
+            if (k < 14) { if (k < 13) wait_vm<12>(); else wait_vm<13>(); }
+            else        { if (k < 15) wait_vm<14>(); else wait_vm<15>(); }
+        }
+    } else {
+        if (k < 24) { if (k < 20) wait_vm<16>(); else wait_vm<20>(); }
+        else        { if (k < 32) wait_vm<24>(); else wait_vm<32>(); }
     }
 }
 
@@ -115,6 +147,10 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
     if (lane < nrows) { my_j0 = p.yj0[p.dst_row0 + rb + lane]; my_fy = p.yfy[p.dst_row0 + rb + lane]; }
     const int dir = p.dypos ? 1 : -1;
     const int my_t0 = p.dypos ? my_j0 : -(my_j0 + 1);          // rows needed: t0, t0+1 in t = dir*row space
+    // vertical weights of the older (t0) and the newer (t0 + 1) row in t space: (1 - fy, fy) when t runs with the
+    // source rows, swapped when it runs against them
+    const double my_wa = p.dypos ? 1 - my_fy : my_fy;
+    const double my_wb = p.dypos ? my_fy : 1 - my_fy;
     {
         int nxt = __shfl_down(my_t0, 1, 64);
         bool mono = (lane + 1 >= nrows) || (nxt >= my_t0);
@@ -171,6 +207,13 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
     const bool in_tail = ((NCH - 1) * CW + EPL * lane) < p.seg;  // lanes of the last chunk inside the slot
     const uint32_t zero_off = 0u;
 
+    // Exact waits: vmcnt retires in issue order (loads, LDS-DMAs and stores alike), so "row t has landed" is "at most
+    // as many VM instructions outstanding as were issued AFTER row t's last DMA".  vm_total counts what this wave has
+    // issued (never more than it really has: an under-count only makes a wait stricter); lane s of `marks` remembers
+    // vm_total just after the DMAs of the row in ring slot s.  Stores are counted only in tiles where every lane
+    // stores with 16-byte stores (then each of the PAIRS store instructions of a row is certain to issue).
+    int vm_total = 0;
+    int marks = 0;
     auto issue_next = [&]() {           // request source row t = treq + 1 into slot t & ns_mask
         ++treq;
         const bool valid = (treq >= tv_lo) && (treq <= tv_hi);
@@ -194,6 +237,8 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
             }
         }
         next_row += row_step;
+        vm_total += NCH;
+        marks = (lane == (treq & ns_mask)) ? vm_total : marks;
     };
 
     const bool vec_store = ((p.nxo % EPL) == 0) && (((uintptr_t)p.dst & 15) == 0);
@@ -215,10 +260,78 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
         }
         return;
     }
+    if (p.flags & 128) {
+        // diagnostics (A/B within one process): the round-2 row loop -- four LDS taps per output value in every output
+        // row, waits that count DMAs only
+        for (int rr = 0; rr < nrows; ++rr) {
+            const int t0 = __builtin_amdgcn_readlane(my_t0, rr);
+            const double fy = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_fy), rr),
+                                               __builtin_amdgcn_readlane(__double2loint(my_fy), rr));
+            {
+                const int ra = (rr + p.pf < nrows) ? rr + p.pf : nrows - 1;
+                int tmax = __builtin_amdgcn_readlane(my_t0, ra) + 1;
+                const int tlim = t0 + p.ns - 1;
+                if (tmax > tlim) tmax = tlim;
+                while (treq < tmax) issue_next();
+            }
+            wait_rows<NCH>(treq - (t0 + 1));
+            const int st = (p.dypos ? t0 : t0 + 1) & ns_mask;
+            const int sb = (p.dypos ? t0 + 1 : t0) & ns_mask;
+            const T* Tp = lds + st * p.seg;
+            const T* Bp = lds + sb * p.seg;
+            const double wy = 1 - fy;
+#pragma unroll
+            for (int q = 0; q < PAIRS; ++q) {
+                alignas(16) T v[EPL];
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    const int d = dloc[q][e];
+                    const double wx = 1 - fx[q][e];
+                    const double top = wx * (double)Tp[d] + fx[q][e] * (double)Tp[d + 1];
+                    const double bot = wx * (double)Bp[d] + fx[q][e] * (double)Bp[d + 1];
+                    v[e] = (T)(wy * top + fy * bot);
+                }
+                T* o = orow + q * CW;
+                if (p.flags & 2) { if (v[0] == (T)1.2345e30) o[0] = v[1]; }
+                else if (vec_store) { if (act[q][0]) *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(v); }
+                else {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) if (act[q][e]) o[e] = v[e];
+                }
+            }
+            orow += p.nxo;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        return;
+    }
+
+    // ---- the row loop.  The horizontal interpolant of a source row at this lane's columns,
+    //          h(t) = (1 - fx) * row_t[d] + fx * row_t[d + 1],
+    // is the `top` of every output row whose upper source row is t and the `bot` of every output row whose lower one
+    // is -- the same operations on the same operands either way -- so it is formed ONCE per source row and kept in
+    // registers: hA = h(th), hB = h(th + 1) in t space.  An output row then costs one vertical blend
+    // (1 - fy) * top + fy * bot; the LDS is read once per source row and tile instead of twice per output row
+    // (2x refinement: a quarter of the LDS reads and half the FP64 work of the tap-per-output form, same bits).
+    double hA[PAIRS][EPL], hB[PAIRS][EPL], wx[PAIRS][EPL];
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { wx[q][e] = 1 - fx[q][e]; hA[q][e] = 0.0; hB[q][e] = 0.0; }
+    auto hrow = [&](int tr, double (&h)[PAIRS][EPL]) {
+        const T* R = lds + (tr & ns_mask) * p.seg;
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int d = dloc[q][e];
+                h[q][e] = wx[q][e] * (double)R[d] + fx[q][e] * (double)R[d + 1];
+            }
+    };
+    const bool count_stores = vec_store && (c0 + TW <= p.nxo) && !(p.flags & (2 | 256));
+    const bool exact_wait = !(p.flags & 256);
+    int th = INT32_MIN / 2;                                     // no row interpolated yet
     for (int rr = 0; rr < nrows; ++rr) {
         const int t0 = __builtin_amdgcn_readlane(my_t0, rr);
-        const double fy = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_fy), rr),
-                                           __builtin_amdgcn_readlane(__double2loint(my_fy), rr));
         // top up the ring: rows up to the farther row of output row rr + pf, but never onto a live slot
         {
             const int ra = (rr + p.pf < nrows) ? rr + p.pf : nrows - 1;
@@ -227,24 +340,36 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
             if (tmax > tlim) tmax = tlim;
             while (treq < tmax) issue_next();
         }
-        wait_rows<NCH>(treq - (t0 + 1));
-
-        const int st = (p.dypos ? t0 : t0 + 1) & ns_mask;      // slot of source row j0 (top)
-        const int sb = (p.dypos ? t0 + 1 : t0) & ns_mask;      // slot of source row j0 + 1 (bottom)
-        const T* Tp = lds + st * p.seg;
-        const T* Bp = lds + sb * p.seg;
-        const double wy = 1 - fy;
+        if (t0 != th) {
+            // rows t0 and t0 + 1 are needed; t0 + 1 was requested last of the two
+            if (exact_wait) wait_vm_upto(vm_total - __builtin_amdgcn_readlane(marks, (t0 + 1) & ns_mask));
+            else wait_rows<NCH>(treq - (t0 + 1));
+            if (t0 == th + 1) {
+#pragma unroll
+                for (int q = 0; q < PAIRS; ++q)
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) hA[q][e] = hB[q][e];
+            } else {
+                hrow(t0, hA);
+            }
+            hrow(t0 + 1, hB);
+            th = t0;
+            // the LDS reads above have returned (their values were consumed); make that explicit before a later DMA
+            // may overwrite their slots
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        // vertical blend.  t runs with the source row when dypos (top = hA) and against it otherwise (top = hB);
+        // (1 - fy) * top + fy * bot is formed as wa * hA + wb * hB with the weights swapped instead of the rows: the
+        // two products are the same and IEEE addition commutes, so the bits are those of the oracle's order.
+        const double wa = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_wa), rr),
+                                           __builtin_amdgcn_readlane(__double2loint(my_wa), rr));
+        const double wb = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_wb), rr),
+                                           __builtin_amdgcn_readlane(__double2loint(my_wb), rr));
 #pragma unroll
         for (int q = 0; q < PAIRS; ++q) {
             alignas(16) T v[EPL];
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                const int d = dloc[q][e];
-                const double wx = 1 - fx[q][e];
-                const double top = wx * (double)Tp[d] + fx[q][e] * (double)Tp[d + 1];
-                const double bot = wx * (double)Bp[d] + fx[q][e] * (double)Bp[d + 1];
-                v[e] = (T)(wy * top + fy * bot);
-            }
+            for (int e = 0; e < EPL; ++e) v[e] = (T)(wa * hA[q][e] + wb * hB[q][e]);
             T* o = orow + q * CW;
             if (p.flags & 2) { if (v[0] == (T)1.2345e30) o[0] = v[1]; }       // diagnostics: keep v live, never store
             else if (vec_store) { if (act[q][0]) *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(v); }
@@ -253,10 +378,8 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
                 for (int e = 0; e < EPL; ++e) if (act[q][e]) o[e] = v[e];
             }
         }
+        if (count_stores) vm_total += PAIRS;
         orow += p.nxo;
-        // the LDS reads above have returned (their values were consumed); make that explicit before a
-        // later DMA may overwrite their slots
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
 
