@@ -17,6 +17,24 @@ def test_smoke_entry():
     g.smoke()
 
 
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` from a bare shell: the parent starts the two ranks itself (rehearsal: both share this
+    GPU over the host-staged gloo transport), relays their one JSON line and their exit code."""
+    env = dict(os.environ, PXL_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--backend", "gloo", "--workload", "cfg2"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "must be launched with" not in r.stderr and "starting 2 ranks" in r.stderr
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
+    assert d["check"]["bit_identical"] and d["check"]["ranks_checked"] == 2
+    assert "gloo" in d["config"]["parallelism"]
+
+
 @pytest.mark.parametrize("workload", ["cfg2", "cfg5", "cfg5:pairs"])
 def test_bench_contract(workload):
     env = dict(os.environ, PXL_BENCH_POINTS="2e6")
@@ -36,6 +54,11 @@ def test_bench_contract(workload):
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     if env.get("PXL_BENCH_SAMPLER") == "pairs":
         assert rf["kernel"] == "k_sample_pairs" and "row-pair" in d["config"]["sampler"]
+        v = d["variants"]           # the same batch with the map fixed (copy reused) and through the direct sampler
+        assert v["map_fixed"]["check"]["bit_identical"] and v["direct"]["check"]["bit_identical"]
+        assert v["map_fixed"]["ms_per_step"] > 0 and v["direct"]["ms_per_step"] > 0
+    if workload == "cfg5":
+        assert d["check"]["bit_identical"] and d["check"]["points_checked"] > 0
     if workload == "cfg2":
         assert d["check"]["bit_identical"] and d["check"]["max_abs_err"] == 0.0
         cb = d["cpu_baseline"]
