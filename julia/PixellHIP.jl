@@ -8,8 +8,12 @@
 module PixellHIP
 
 using Pixell
-import Pixell: Enmap, AbstractCARWCS, CarClenshawCurtis, getwcs, pix2sky, pix2sky!, sky2pix, sky2pix!, posmap,
-               pixareamap!, rewind!, unwind!
+import Pixell: Enmap, AbstractCARWCS, CarClenshawCurtis, Gnomonic, getwcs, pix2sky, pix2sky!, sky2pix, sky2pix!, posmap,
+               pixareamap!, rewind, rewind!, unwind, unwind!, read_map, write_map
+using WCS: WCSTransform
+import WCS
+using FITSIO: FITS, read_header
+using Printf: @sprintf
 
 const libpixell_hip = get(ENV, "PIXELL_HIP_LIB", "libpixell_hip.so")
 const libhip = "libamdhip64.so"
@@ -22,6 +26,11 @@ struct CarWCS
     unit::Cdouble
 end
 CarWCS(w::AbstractCARWCS) = CarWCS(Float64.(w.cdelt), Float64.(w.crpix), Float64.(w.crval), Float64(w.unit))
+# Gnomonic{T} has the same four fields (tan_proj.jl:4-9); the C side takes it through the same struct
+CarWCS(w::Gnomonic) = CarWCS(Float64.(w.cdelt), Float64.(w.crpix), Float64.(w.crval), Float64(w.unit))
+const AnyFastWCS = Union{AbstractCARWCS,Gnomonic}
+projcode(::AbstractCARWCS) = Cint(0)                           # PXL_PROJ_CAR
+projcode(::Gnomonic) = Cint(1)                                 # PXL_PROJ_TAN
 
 function check(rc::Cint)
     rc == 0 && return nothing
@@ -58,7 +67,14 @@ function Base.Array(d::HIPArray{T,N}) where {T,N}
     h
 end
 
+function Base.copy(d::HIPArray{T,N}) where {T,N}            # device-to-device (hipMemcpyDeviceToDevice = 3)
+    c = HIPArray{T,N}(undef, d.dims)
+    GC.@preserve d c ccall((:hipMemcpy, libhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), c.ptr, d.ptr, prod(d.dims) * sizeof(T), 3)
+    c
+end
+
 const DevCoords = HIPArray{Float64,2}                      # 2xN, interleaved pairs (car_proj.jl:102-107)
+const DevVector = HIPArray{Float64,1}
 const NULLSTREAM = C_NULL
 
 # ---- pix2sky! / sky2pix! for 2xN device batches: same signatures and `safe` keyword as car_proj.jl:92,165
@@ -83,6 +99,58 @@ end
 Pixell.sky2pix(shape, wcs::AbstractCARWCS, sky::DevCoords; safe=true) =
     sky2pix!(shape, wcs, sky, similar(sky); safe=safe)
 
+# ---- pix2sky(shape, wcs, ra_pixel, dec_pixel; safe) on two device N-vectors (car_proj.jl:141-152: the broadcast form;
+#      safe -> rewind, as the reference's FIXME leaves it).  Without this method a HIPArray falls into the reference's
+#      broadcast and stops at the scalar-indexing error.
+function Pixell.pix2sky(shape, wcs::AbstractCARWCS, ra_pixel::DevVector, dec_pixel::DevVector; safe=true)
+    @assert length(ra_pixel) == length(dec_pixel)
+    ra, dec = similar(ra_pixel), similar(dec_pixel)
+    GC.@preserve ra_pixel dec_pixel ra dec check(ccall((:pxl_pix2sky_car_soa_f64, libpixell_hip), Cint,
+        (Ref{CarWCS}, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cvoid}),
+        CarWCS(wcs), length(ra_pixel), ra_pixel.ptr, dec_pixel.ptr, ra.ptr, dec.ptr, safe, NULLSTREAM))
+    return ra, dec
+end
+
+# ---- sky2pix(shape, wcs, ra::AV, dec::AV; safe) on two device N-vectors (car_proj.jl:235-252: reciprocal form with the
+#      period abs(2pi * (1/d)), PXL_FORM_RECIP_AV = 2)
+function Pixell.sky2pix(shape, wcs::AbstractCARWCS, ra::DevVector, dec::DevVector; safe=true)
+    @assert length(ra) == length(dec)
+    pix_ra, pix_dec = similar(ra), similar(dec)
+    shp = Int64[shape[1], shape[2]]
+    GC.@preserve ra dec pix_ra pix_dec shp check(ccall((:pxl_sky2pix_car_soa_f64, libpixell_hip), Cint,
+        (Ref{CarWCS}, Ptr{Int64}, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Ptr{Cvoid}),
+        CarWCS(wcs), shp, length(ra), ra.ptr, dec.ptr, pix_ra.ptr, pix_dec.ptr, safe, 2, NULLSTREAM))
+    return pix_ra, pix_dec
+end
+
+# ---- Gnomonic evaluators over device N-vectors (tan_proj.jl:44-75; the reference has the scalar methods only and
+#      ignores `safe`, so does the library)
+function Pixell.sky2pix(shape, wcs::Gnomonic, ra::DevVector, dec::DevVector; safe=false)
+    @assert length(ra) == length(dec)
+    x, y = similar(ra), similar(dec)
+    GC.@preserve ra dec x y check(ccall((:pxl_sky2pix_tan_f64, libpixell_hip), Cint,
+        (Ref{CarWCS}, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cvoid}),
+        CarWCS(wcs), length(ra), ra.ptr, dec.ptr, x.ptr, y.ptr, NULLSTREAM))
+    return x, y
+end
+function Pixell.pix2sky(shape, wcs::Gnomonic, ra_pixel::DevVector, dec_pixel::DevVector; safe=false)
+    @assert length(ra_pixel) == length(dec_pixel)
+    ra, dec = similar(ra_pixel), similar(dec_pixel)
+    GC.@preserve ra_pixel dec_pixel ra dec check(ccall((:pxl_pix2sky_tan_f64, libpixell_hip), Cint,
+        (Ref{CarWCS}, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cvoid}),
+        CarWCS(wcs), length(ra_pixel), ra_pixel.ptr, dec_pixel.ptr, ra.ptr, dec.ptr, NULLSTREAM))
+    return ra, dec
+end
+# posmap(shape, wcs::Gnomonic) (enmap_ops.jl:190-203 over tan_proj.jl:59-75) into device maps
+function posmap_device(shape::Tuple{Int,Int}, wcs::Gnomonic)
+    ra, dec = HIPArray{Float64}(undef, shape...), HIPArray{Float64}(undef, shape...)
+    shp = Int64[shape...]
+    GC.@preserve ra dec shp check(ccall((:pxl_posmap_tan_f64, libpixell_hip), Cint,
+        (Ref{CarWCS}, Ptr{Int64}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cvoid}),
+        CarWCS(wcs), shp, 0, shape[2], ra.ptr, dec.ptr, NULLSTREAM))
+    return Enmap(ra, wcs), Enmap(dec, wcs)
+end
+
 # ---- posmap on the device (enmap_ops.jl:190-203): returns two device Enmaps
 function posmap_device(shape::Tuple{Int,Int}, wcs::AbstractCARWCS)
     ra, dec = HIPArray{Float64}(undef, shape...), HIPArray{Float64}(undef, shape...)
@@ -104,6 +172,26 @@ function reproject(m::Enmap{Float64,N,<:HIPArray,<:AbstractCARWCS}, shape_out::T
     GC.@preserve src out shp_in shp_out check(ccall((:pxl_reproject_car_bilinear_f64, libpixell_hip), Cint,
         (Ref{CarWCS}, Ptr{Int64}, Ptr{Cdouble}, Ref{CarWCS}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Cvoid}),
         CarWCS(getwcs(m)), shp_in, src.ptr, CarWCS(wcs_out), shp_out, out.ptr, NULLSTREAM))
+    return Enmap(out, wcs_out)
+end
+
+# ---- CAR <-> Gnomonic (and TAN -> TAN): the non-separable reprojection, pix2sky(out) -> sky2pix(in) -> 2x2 gather with
+#      the evaluators of car_proj.jl / tan_proj.jl.  Picked by dispatch when either side is a Gnomonic WCS.
+function reproject(m::Enmap{Float64,N,<:HIPArray,<:AnyFastWCS}, shape_out::Tuple{Int,Int}, wcs_out::Gnomonic) where {N}
+    return reproject_generic(m, shape_out, wcs_out)
+end
+function reproject(m::Enmap{Float64,N,<:HIPArray,<:Gnomonic}, shape_out::Tuple{Int,Int}, wcs_out::AbstractCARWCS) where {N}
+    return reproject_generic(m, shape_out, wcs_out)
+end
+function reproject_generic(m::Enmap{Float64,N,<:HIPArray}, shape_out::Tuple{Int,Int}, wcs_out::AnyFastWCS) where {N}
+    nc = N == 3 ? size(m, 3) : 1
+    out = HIPArray{Float64}(undef, shape_out..., (N == 3 ? (nc,) : ())...)
+    shp_in, shp_out = Int64[size(m, 1), size(m, 2), nc], Int64[shape_out...]
+    src = parent(m)
+    win = getwcs(m)
+    GC.@preserve src out shp_in shp_out check(ccall((:pxl_reproject_generic_bilinear_f64, libpixell_hip), Cint,
+        (Ref{CarWCS}, Cint, Ptr{Int64}, Ptr{Cdouble}, Ref{CarWCS}, Cint, Ptr{Int64}, Ptr{Cdouble}, Ptr{Cvoid}),
+        CarWCS(win), projcode(win), shp_in, src.ptr, CarWCS(wcs_out), projcode(wcs_out), shp_out, out.ptr, NULLSTREAM))
     return Enmap(out, wcs_out)
 end
 
@@ -194,6 +282,11 @@ function Pixell.rewind!(angles::HIPArray{Float64}; period=2π, ref_angle=0.0)
     return angles
 end
 
+# the non-mutating forms (enmap_ops.jl:10-13, 21-24) copy on the device and work in place on the copy
+Pixell.rewind(angles::HIPArray{Float64}; period=2π, ref_angle=0.0) = rewind!(copy(angles); period=period, ref_angle=ref_angle)
+Pixell.unwind(angles::HIPArray{Float64,N}; dims=N, period=2π, ref_angle=0.0) where {N} =
+    unwind!(copy(angles); dims=dims, period=period, ref_angle=ref_angle)
+
 # dims = 2 on a 2xN batch (what pix2sky! uses, car_proj.jl:111) or a plain vector
 function Pixell.unwind!(angles::HIPArray{Float64,N}; dims=N, period=2π, ref_angle=0.0) where {N}
     @assert (N == 1) || (N == 2 && size(angles, 1) == 2 && dims == 2) "device unwind! handles vectors and 2xN batches along N"
@@ -202,6 +295,87 @@ function Pixell.unwind!(angles::HIPArray{Float64,N}; dims=N, period=2π, ref_ang
         (Ptr{Cdouble}, Int64, Cint, Cdouble, Cdouble, Ptr{Cvoid}),
         angles.ptr, N == 1 ? length(angles) : size(angles, 2), nrow, period, ref_angle, NULLSTREAM))
     return angles
+end
+
+# ---- read_map / write_map with the image in HBM (enmap.jl:198-237).  The header goes through FITSIO / WCS exactly as in
+#      the reference (same WCS conversion, same POLCCONV rule incl. its linear-indexing slip that also negates I); the data
+#      block -- big-endian BITPIX -64 or -32, NAXIS1 = RA fastest, i.e. already Julia's layout -- is read raw, copied to the
+#      device and byte-swapped there (pxl_fits_decode_f64).  Primary HDU, whole image (`sel` stays with the CPU method).
+function fits_data_offset(path::String)
+    open(path, "r") do io
+        block = Vector{UInt8}(undef, 2880)
+        off = 0
+        while true
+            read!(io, block)
+            off += 2880
+            for c in 0:35
+                String(block[80c+1:80c+8]) == "END     " && return off
+            end
+        end
+    end
+end
+function Pixell.read_map(path::String, ::Type{HIPArray}; verbose=true)
+    f = FITS(path, "r")
+    header = read_header(f[1])
+    close(f)
+    bitpix = header["BITPIX"]
+    @assert bitpix == -64 || bitpix == -32 "device read_map handles BITPIX -64 / -32 images"
+    dims = ntuple(i -> Int(header["NAXIS$i"]), header["NAXIS"])
+    n = prod(dims)
+    raw = Vector{UInt8}(undef, n * (abs(bitpix) ÷ 8))
+    open(path, "r") do io
+        seek(io, fits_data_offset(path))
+        read!(io, raw)
+    end
+    if "STOKES" in header.values && get(header, "POLCCONV", "COSMO") == "IAU"
+        # resolve_polcconv! (enmap.jl:178-195) as the reference executes it: `signs[signs_size] .= -1` is a linear index,
+        # so planes 1 AND 3 of the STOKES axis change sign.  Done on the raw big-endian bytes before the upload: the sign
+        # bit of an IEEE number is the top bit of its first byte.
+        verbose && println("convert to IAU: flip U (and, like the reference, I)")
+        esz = abs(bitpix) ÷ 8
+        plane = dims[1] * dims[2]
+        for c in (1, 3)
+            c * plane <= n || continue
+            @inbounds for k in (c - 1) * plane : c * plane - 1
+                raw[esz * k + 1] ⊻= 0x80
+            end
+        end
+    end
+    draw = HIPArray(raw)
+    data = HIPArray{Float64}(undef, dims...)
+    GC.@preserve draw data check(ccall((:pxl_fits_decode_f64, libpixell_hip), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Int64, Cint, Ptr{Cvoid}), draw.ptr, data.ptr, n, bitpix, NULLSTREAM))
+    header_str = join([@sprintf("%-80s", l) for l in split(string(header), "\n")])
+    wcs0 = WCS.from_header(header_str)[1]
+    @assert wcs0.ctype[1] == "RA---CAR" && wcs0.ctype[2] == "DEC--CAR"
+    wcs = convert(CarClenshawCurtis{Float64}, wcs0)
+    return Enmap(data, wcs)
+end
+
+function Pixell.write_map(fname::String, emap::Enmap{Float64,N,<:HIPArray}) where {N}
+    data = parent(emap)
+    n = length(data)
+    draw = HIPArray{UInt8}(undef, 8n)
+    GC.@preserve data draw check(ccall((:pxl_fits_encode_f64, libpixell_hip), Cint,
+        (Ptr{Cdouble}, Ptr{Cvoid}, Int64, Ptr{Cvoid}), data.ptr, draw.ptr, n, NULLSTREAM))
+    raw = Array(draw)
+    cards = String[@sprintf("%-8s= %20s", "SIMPLE", "T"), @sprintf("%-8s= %20d", "BITPIX", -64), @sprintf("%-8s= %20d", "NAXIS", N)]
+    for i in 1:N
+        push!(cards, @sprintf("%-8s= %20d", "NAXIS$i", size(data, i)))
+    end
+    push!(cards, @sprintf("%-8s= %20s", "EXTEND", "T"))
+    header = WCS.to_header(Base.convert(WCSTransform, getwcs(emap)))       # the reference's own card source (enmap.jl:229)
+    append!(cards, [header[1+(i-1)*80:i*80] for i in 1:round(Int, length(header) / 80)])
+    push!(cards, "END")
+    open(fname, "w") do io
+        for c in cards
+            write(io, rpad(c, 80)[1:80])
+        end
+        write(io, " "^(mod(-80 * length(cards), 2880)))
+        write(io, raw)
+        write(io, zeros(UInt8, mod(-length(raw), 2880)))
+    end
+    return nothing
 end
 
 # ---- one step of the dec-strip sharded operator on this rank (one process per GPU): the library exchanges the halo
@@ -241,6 +415,6 @@ sharded_step!(dst, plan, src, own_rows, sends, recvs, comm::PxlComm) = sharded_s
 comm_destroy(c::PxlComm) = check(ccall((:pxl_comm_destroy, libpixell_hip), Cint, (Ptr{Cvoid},), c.handle))
 comm_backend() = unsafe_string(ccall((:pxl_comm_backend, libpixell_hip), Cstring, ()))
 
-export HIPArray, posmap_device, reproject, reproject!, ReprojectPlan, sample_bilinear, SamplePairs, HaloXfer, sharded_step!
+export HIPArray, posmap_device, reproject, reproject_generic, reproject!, ReprojectPlan, sample_bilinear, SamplePairs, HaloXfer, sharded_step!
 export PxlComm, comm_unique_id, comm_init_rank, comm_destroy, comm_backend
 end # module

@@ -78,3 +78,59 @@ end
     ang = cumsum(1.5 .* randn(2, 50_000), dims=2)
     @test Array(unwind!(HIPArray(copy(ang)); dims=2)) == unwind!(copy(ang); dims=2)
 end
+
+@testset "two-vector forms (car_proj.jl:141-152, 235-252) against the reference's CPU methods, bit for bit" begin
+    shape, wcs = fullsky_geometry(deg2rad(1))
+    ip, jp = 400 .* rand(100_000) .- 20, 200 .* rand(100_000) .- 10
+    for safe in (true, false)
+        ra, dec = pix2sky(shape, wcs, HIPArray(ip), HIPArray(jp); safe=safe)
+        ra0, dec0 = pix2sky(shape, wcs, ip, jp; safe=safe)
+        @test Array(ra) == ra0 && Array(dec) == dec0
+        x, y = sky2pix(shape, wcs, HIPArray(ra0), HIPArray(dec0); safe=safe)       # the ::AV method: reciprocal-period form
+        x0, y0 = sky2pix(shape, wcs, ra0, dec0; safe=safe)
+        @test Array(x) == x0 && Array(y) == y0
+    end
+    # docstring literals: (30, 80) -> (151 deg, -11 deg); (30 deg, 80 deg) -> (151, 171)   car_proj.jl:137-138, 216-217
+    ra, dec = pix2sky(shape, wcs, HIPArray([30.0]), HIPArray([80.0]))
+    @test rad2deg.([Array(ra)[1], Array(dec)[1]]) ≈ [151.0, -11.0]
+    x, y = sky2pix(shape, wcs, HIPArray([deg2rad(30.0)]), HIPArray([deg2rad(80.0)]))
+    @test [Array(x)[1], Array(y)[1]] ≈ [151.0, 171.0]
+end
+
+@testset "Gnomonic evaluators and posmap (tan_proj.jl:44-75; test_geometry.jl:92-119)" begin
+    wcs = Pixell.Gnomonic{Float64}((-0.004166666666666667, 0.004166666666666667), (914.0, 913.0), (53.0, -28.0), π / 180)
+    shape = (1827, 1825)
+    ra, dec = PixellHIP.posmap_device(shape, wcs)
+    ra0, dec0 = posmap(shape, wcs)
+    # the reference's own bound for its fast Gnomonic path against wcslib: summed absolute difference below 1e-9
+    @test sum(abs.(Array(parent(ra)) .- parent(ra0))) < 1e-9
+    @test sum(abs.(Array(parent(dec)) .- parent(dec0))) < 1e-9
+    i, j = 1800 .* rand(10_000), 1800 .* rand(10_000)
+    a, d = pix2sky(shape, wcs, HIPArray(i), HIPArray(j))
+    a0 = [pix2sky(shape, wcs, i[k], j[k])[1] for k in eachindex(i)]
+    @test maximum(abs.(Array(a) .- a0)) < 1e-13
+    x, y = sky2pix(shape, wcs, a, d)
+    @test maximum(abs.(Array(x) .- i)) < 1e-8 && maximum(abs.(Array(y) .- j)) < 1e-8
+end
+
+@testset "CAR <-> Gnomonic reprojection, non-mutating rewind / unwind, FITS round trip" begin
+    shape, wcs = fullsky_geometry(2π / 2160)
+    m = Enmap(HIPArray(ones(shape...)), wcs)
+    tan = Pixell.Gnomonic{Float64}((-1 / 6, 1 / 6), (128.5, 128.5), (30.0, 10.0), π / 180)
+    patch = PixellHIP.reproject(m, (256, 256), tan)                     # picked by dispatch on the Gnomonic output WCS
+    @test maximum(abs.(Array(parent(patch)) .- 1)) < 1e-12
+    back = PixellHIP.reproject(patch, shape, wcs)                       # Gnomonic -> CAR: ones inside the patch, zeros outside
+    @test all(x -> abs(x) < 1e-12 || abs(x - 1) < 1e-9 || 0 <= x <= 1, Array(parent(back)))
+    ang = 40 .* rand(2, 10_000) .- 20
+    d = HIPArray(ang)
+    @test Array(rewind(d)) == rewind(ang) && Array(d) == ang            # the input is left alone (enmap_ops.jl:10-13)
+    @test Array(unwind(d; dims=2)) == unwind(ang; dims=2) && Array(d) == ang
+    path = joinpath(mktempdir(), "roundtrip.fits")
+    src = randn(shape...)
+    write_map(path, Enmap(HIPArray(src), wcs))                          # big-endian encode on the device
+    @test parent(read_map(path)) == src                                 # the reference's CPU reader sees the same map
+    dm = read_map(path, HIPArray)
+    @test Array(parent(dm)) == src && getwcs(dm) == getwcs(read_map(path))
+    ref = read_map(joinpath(@__DIR__, "..", "tests", "golden", "test.fits"))   # the reference's own fixture (test/data/test.fits)
+    @test Array(parent(read_map(joinpath(@__DIR__, "..", "tests", "golden", "test.fits"), HIPArray))) == parent(ref)
+end

@@ -34,22 +34,98 @@ def test_library_exports_every_declared_symbol(pj):
     assert sorted(pj._lib.SIGNATURES) == declared_symbols()
 
 
-def test_julia_binding_only_calls_declared_symbols(pj):
-    """julia/PixellHIP.jl (the binding a Pixell.jl maintainer would add, INTEGRATION.md) must ccall entry points that the
-    header declares and the library exports, with as many argument types as the C prototype has parameters."""
-    text = open(os.path.join(ROOT, "julia", "PixellHIP.jl")).read()
+def _c_prototypes():
+    """name -> (return type, [parameter types]) from include/pixell_hip.h, each type reduced to a canonical spelling:
+    qualifiers and parameter names dropped, `T name[k]` read as `T*`."""
     header = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    protos = {}
+    for ret, name, params in re.findall(r"^\s*([A-Za-z_][\w \t\*]*?)\s*\b(pxl_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", header, flags=re.M):
+        def canon(decl, is_param):
+            decl = decl.strip()
+            stars = decl.count("*") + len(re.findall(r"\[[^\]]*\]", decl))
+            decl = re.sub(r"\[[^\]]*\]", "", decl).replace("*", " ")
+            toks = [t for t in decl.split() if t not in ("const", "struct")]
+            if is_param and len(toks) > 1:
+                toks = toks[:-1]                      # the parameter's name
+            return " ".join(toks) + "*" * stars
+        plist = [] if params.strip() in ("", "void") else [canon(q, True) for q in params.split(",")]
+        protos[name] = (canon(ret, False), plist)
+    return protos
+
+
+# what each Julia ccall type may stand for on the C side (opaque handles travel as Ptr{Cvoid})
+_JULIA_TO_C = {
+    "Ref{CarWCS}": {"pxl_car_wcs*"},
+    "Int64": {"int64_t"}, "Cint": {"int"}, "Cdouble": {"double"}, "Csize_t": {"size_t"},
+    "Ptr{Cdouble}": {"double*"}, "Ptr{Cfloat}": {"float*"}, "Ptr{Int64}": {"int64_t*"},
+    "Ptr{Cvoid}": {"void*", "pxl_reproject_plan*"},
+    "Ptr{Ptr{Cvoid}}": {"void**", "pxl_reproject_plan**"},
+    "Ptr{UInt8}": {"char*", "void*"},
+    "Ptr{HaloXfer}": {"pxl_halo_xfer*"},
+    "Cstring": {"char*"},
+}
+
+
+def _split_julia_types(argtypes):
+    out, depth, cur = [], 0, ""
+    for ch in argtypes:
+        if ch == "{":
+            depth += 1
+        elif ch == "}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def test_julia_binding_matches_the_c_prototypes(pj):
+    """julia/PixellHIP.jl (the binding a Pixell.jl maintainer would add, INTEGRATION.md) must ccall entry points that the
+    header declares and the library exports, and every ccall's return type and argument TYPES must be the C prototype's
+    (Ref{CarWCS} <-> const pxl_car_wcs*, Int64 <-> int64_t, Cint <-> int, Ptr{Cdouble} <-> double*, ...): a Cint where
+    the C side takes an int64_t would corrupt the call silently."""
+    text = open(os.path.join(ROOT, "julia", "PixellHIP.jl")).read()
     lib = ctypes.CDLL(pj.library_path())
-    calls = re.findall(r"ccall\(\(:(pxl_[a-z0-9_]+), libpixell_hip\),\s*\w+,\s*\(([^)]*)\)", text, flags=re.S)
-    assert len(calls) >= 20
-    declared = declared_symbols()
-    for name, argtypes in calls:
-        assert name in declared, "PixellHIP.jl calls %s, which include/pixell_hip.h does not declare" % name
+    protos = _c_prototypes()
+    assert sorted(protos) == declared_symbols()
+    calls = re.findall(r"ccall\(\(:(pxl_[a-z0-9_]+), libpixell_hip\),\s*([\w{}]+),\s*\(([^)]*)\)", text, flags=re.S)
+    assert len(calls) >= 28
+    for name, jret, argtypes in calls:
+        assert name in protos, "PixellHIP.jl calls %s, which include/pixell_hip.h does not declare" % name
         assert hasattr(lib, name)
-        proto = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, header, flags=re.S).group(1)
-        nparams = 0 if proto.strip() in ("", "void") else len(proto.split(","))
-        nargs = len([a for a in argtypes.split(",") if a.strip()])
-        assert nargs == nparams, "%s: %d Julia argument types for %d C parameters" % (name, nargs, nparams)
+        cret, cparams = protos[name]
+        jargs = _split_julia_types(argtypes)
+        assert len(jargs) == len(cparams), "%s: %d Julia argument types for %d C parameters" % (name, len(jargs), len(cparams))
+        assert cret in _JULIA_TO_C[jret], "%s returns %s in C, %s in the ccall" % (name, cret, jret)
+        for k, (jt, ct) in enumerate(zip(jargs, cparams)):
+            assert jt in _JULIA_TO_C, "%s argument %d: unknown Julia type %s" % (name, k + 1, jt)
+            assert ct in _JULIA_TO_C[jt], "%s argument %d: C takes %s, the ccall passes %s" % (name, k + 1, ct, jt)
+    # the methods INTEGRATION.md's table promises exist, on the reference's own generic functions
+    for sig in (r"Pixell\.pix2sky!\(shape, wcs::AbstractCARWCS, pix::DevCoords", r"Pixell\.sky2pix!\(shape, wcs::AbstractCARWCS, sky::DevCoords",
+                r"Pixell\.pix2sky\(shape, wcs::AbstractCARWCS, ra_pixel::DevVector, dec_pixel::DevVector",
+                r"Pixell\.sky2pix\(shape, wcs::AbstractCARWCS, ra::DevVector, dec::DevVector",
+                r"Pixell\.sky2pix\(shape, wcs::Gnomonic, ra::DevVector", r"Pixell\.pix2sky\(shape, wcs::Gnomonic, ra_pixel::DevVector",
+                r"posmap_device\(shape::Tuple\{Int,Int\}, wcs::Gnomonic\)", r"function reproject_generic\(",
+                r"Pixell\.read_map\(path::String, ::Type\{HIPArray\}", r"Pixell\.write_map\(fname::String, emap::Enmap\{Float64,N,<:HIPArray\}\)",
+                r"Pixell\.rewind\(angles::HIPArray", r"Pixell\.unwind\(angles::HIPArray", r"Pixell\.pixareamap!\("):
+        assert re.search(sig, text), "PixellHIP.jl lacks the method %s" % sig
+
+
+def test_julia_structs_mirror_the_c_structs():
+    """CarWCS == pxl_car_wcs (7 doubles) and HaloXfer == pxl_halo_xfer (int32, int32, int64, int64), field for field."""
+    text = open(os.path.join(ROOT, "julia", "PixellHIP.jl")).read()
+    car = re.search(r"struct CarWCS\n(.*?)\nend", text, flags=re.S).group(1)
+    assert [ln.split("::")[1].strip() for ln in car.strip().splitlines()] == ["NTuple{2,Cdouble}"] * 3 + ["Cdouble"]
+    halo = re.search(r"struct HaloXfer[^\n]*\n(.*?)\nend", text, flags=re.S).group(1)
+    fields = [ln.split("#")[0].split("::")[1].strip() for ln in halo.strip().splitlines()]
+    assert fields == ["Int32", "Int32", "Int64", "Int64"]
+    header = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    chalo = re.search(r"typedef struct pxl_halo_xfer \{(.*?)\}", header, flags=re.S).group(1)
+    assert [d.split()[0] for d in chalo.split(";") if d.strip()] == ["int32_t", "int32_t", "int64_t", "int64_t"]
 
 
 def test_version_and_error_channel_without_gpu(pj):
