@@ -253,33 +253,6 @@ int pxl_sample_car_bilinear_pairs_f32(const pxl_car_wcs* wcs_in, const int64_t s
                                       int64_t src_row0, int64_t src_nrows,
                                       int64_t n, const double* sky2xN, float* out, void* stream);
 
-/* ---- Tile-binned scattered sampler: the same (x, y) = sky2pix!(...; safe=true) + 2x2 gather as
- *      pxl_sample_car_bilinear_*, bit-identical results, with the points counted and scattered into map tiles of
- *      about one L2's worth, gathered tile by tile, and the values returned to the caller's order.
- *      The plan owns the workspace (24 + 8 nc bytes per point of nmax for Float64 maps, plus tables); nmax < 2^32.
- *      elem_bytes = 8 (Float64 map) or 4 (Float32).  src/out as in pxl_sample_car_bilinear_*; n <= nmax.
- *      Knobs read at plan creation: PXL_SAMPLE_{TILE_KB,TH,PT,SEGS,VMAJOR,TRIPS,GATHER,RT,LDS_KB,DMA}.  Measured on
- *      MI355X: 51 ms per 1e9 points against 53.7 ms for the direct entry -- every per-point divergent
- *      access costs about the same whatever level it hits, and this pipeline has six per point against four -- so the
- *      direct entry stays the default.  No reference counterpart (the reference has no sampler).  */
-typedef struct pxl_sample_plan pxl_sample_plan;
-int pxl_sample_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], int64_t src_row0, int64_t src_nrows,
-                           int64_t nmax, int elem_bytes, pxl_sample_plan** plan);
-int64_t pxl_sample_plan_workspace_bytes(const pxl_sample_plan* plan);          /* -1 on a null plan */
-int pxl_sample_plan_tiles(const pxl_sample_plan* plan, int32_t* tile_w, int32_t* tile_h, int32_t* ntiles);
-int pxl_sample_plan_execute_f64(pxl_sample_plan* plan, const double* src, int64_t n, const double* sky2xN,
-                                double* out, void* stream);
-int pxl_sample_plan_execute_f32(pxl_sample_plan* plan, const float* src, int64_t n, const double* sky2xN,
-                                float* out, void* stream);
-/* The two halves of execute, for a batch that is sampled more than once (the same pointing against several maps, or
- * against a map that changes between iterations): bind = count + scatter of the points into tiles (the plan keeps the
- * records and slots: 20 of the 51 ms of an execute at 1e9 points), sample_bound = gather + un-permute of the bound batch
- * from `src` (any map of the plan's geometry) into `out`.  execute(n, sky) == bind(n, sky) + sample_bound.            */
-int pxl_sample_plan_bind(pxl_sample_plan* plan, int64_t n, const double* sky2xN, void* stream);
-int pxl_sample_plan_sample_bound_f64(pxl_sample_plan* plan, const double* src, double* out, void* stream);
-int pxl_sample_plan_sample_bound_f32(pxl_sample_plan* plan, const float* src, float* out, void* stream);
-int pxl_sample_plan_destroy(pxl_sample_plan* plan);
-
 /* ---- FITS image staging (the on-disk format either side of the path: read_map / write_map, enmap.jl:198-237).
  *      raw_be: device copy of the HDU's big-endian data block, n elements of BITPIX -64 (or -32 for decode);
  *      decode writes native Float64 (in place allowed for -64), encode writes big-endian Float64.          */

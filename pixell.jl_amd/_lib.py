@@ -74,15 +74,6 @@ SIGNATURES = {
     "pxl_sample_build_pairs_f32": (C.c_int, [_SHP, _P, _I64, _P, _P]),
     "pxl_sample_car_bilinear_pairs_f64": (C.c_int, [_WP, _SHP, _P, _I64, _I64, _I64, _P, _P, _P]),
     "pxl_sample_car_bilinear_pairs_f32": (C.c_int, [_WP, _SHP, _P, _I64, _I64, _I64, _P, _P, _P]),
-    "pxl_sample_plan_create": (C.c_int, [_WP, _SHP, _I64, _I64, _I64, C.c_int, C.POINTER(_P)]),
-    "pxl_sample_plan_workspace_bytes": (_I64, [_P]),
-    "pxl_sample_plan_tiles": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
-    "pxl_sample_plan_execute_f64": (C.c_int, [_P, _P, _I64, _P, _P, _P]),
-    "pxl_sample_plan_execute_f32": (C.c_int, [_P, _P, _I64, _P, _P, _P]),
-    "pxl_sample_plan_bind": (C.c_int, [_P, _I64, _P, _P]),
-    "pxl_sample_plan_sample_bound_f64": (C.c_int, [_P, _P, _P, _P]),
-    "pxl_sample_plan_sample_bound_f32": (C.c_int, [_P, _P, _P, _P]),
-    "pxl_sample_plan_destroy": (C.c_int, [_P]),
     "pxl_fits_decode_f64": (C.c_int, [_P, _P, _I64, C.c_int, _P]),
     "pxl_fits_encode_f64": (C.c_int, [_P, _P, _I64, _P]),
     "pxl_fits_swap_f32": (C.c_int, [_P, _P, _I64, _P]),

@@ -10,7 +10,6 @@
 //   pxl_maps.h           posmap, pixareamap                   pxl_tan.h        Gnomonic evaluators
 //   pxl_reproject.h      tables, gather + register-staged     pxl_reproject_dma.h  the LDS-DMA kernel (fast path)
 //   pxl_sample.h         CAR<->TAN reprojection, sampler      pxl_misc.h       FITS staging, synthetic data
-//   pxl_sample_binned.h  tile-binned scattered sampler (count / scan / scatter / gather / un-permute)
 // This file keeps the error plumbing and the extern "C" entry points.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared   (csrc/Makefile)
@@ -83,7 +82,6 @@ static int env_int(const char* name, int dflt) {
 #include "pxl_reproject.h"
 #include "pxl_reproject_dma.h"
 #include "pxl_sample.h"
-#include "pxl_sample_binned.h"
 #include "pxl_misc.h"
 #include "pxl_rccl.h"
 
@@ -1143,272 +1141,6 @@ int pxl_sample_car_bilinear_pairs_f32(const pxl_car_wcs* wcs_in, const int64_t s
                                       int64_t src_row0, int64_t src_nrows, int64_t n, const double* sky, float* out,
                                       void* stream) {
     return sample_pairs_impl(wcs_in, shape_in, pairs, src_row0, src_nrows, n, sky, out, stream, 4);
-}
-
-// ---- tile-binned scattered sampler (pxl_sample_binned.h): a plan owns the workspace (records, slots, values, tables)
-struct pxl_sample_plan {
-    pxl_car_wcs w;
-    int64_t nx, ny, nc, row0, nrows, nmax;
-    int periodic, device, dtype;
-    BinGrid g;
-    int pt;                 // points per thread of the count / scatter kernels: chunk = pt * 1024 points
-    int segs, vmajor, trips;
-    int gather;             // 0 = direct taps out of L2 (k_sample_binned, default: the fastest measured),
-                            // 1 = records in registers, source strips streamed through LDS by LDS-DMA (k_sample_tile_regs)
-    int rt;                 // records per thread of the LDS form
-    uint32_t* wstart; uint32_t* item; int64_t items_max;
-    int64_t bound_n;        // points of the batch whose records / slots the workspace holds (-1: none)
-    bool dma_ok;            // geometry allows 16-byte LDS-DMA staging (nx and tile width multiples of 16 B)
-    void* zero_page;
-    int sh, ns, pitch;      // strip height (source rows), strips per tile, LDS row pitch in elements
-    int64_t wmax;           // chunks at nmax
-    double2* rec; uint32_t* slot; void* val; uint16_t* cnt; uint32_t* off; uint32_t* seg; uint32_t* start;
-    size_t bytes;
-};
-
-static void sample_plan_free(pxl_sample_plan* pl) {
-    void* ptrs[] = {pl->rec, pl->slot, pl->val, pl->cnt, pl->off, pl->seg, pl->start, pl->wstart, pl->item, pl->zero_page};
-    for (void* q : ptrs) if (q) (void)hipFree(q);
-    delete pl;
-}
-
-int pxl_sample_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[3], int64_t src_row0, int64_t src_nrows,
-                           int64_t nmax, int elem_bytes, pxl_sample_plan** out) {
-    if (!out) return fail(PXL_EINVAL, "sample_plan_create: null plan pointer");
-    *out = nullptr;
-    if (!wcs_ok(wcs_in) || !shape_in) return fail(PXL_EINVAL, "sample_plan_create: invalid WCS/shape");
-    if (shape_in[0] < 1 || shape_in[1] < 1 || shape_in[2] < 1) return fail(PXL_EINVAL, "sample_plan_create: shapes must be positive");
-    if (shape_in[0] > 1000000000 || shape_in[1] > 1000000000) return fail(PXL_EINVAL, "sample_plan_create: axis too long (1e9 pixels)");
-    if (src_row0 < 0 || src_nrows < 0 || src_row0 + src_nrows > shape_in[1]) return fail(PXL_EINVAL, "sample_plan_create: source window outside the map");
-    if (elem_bytes != 4 && elem_bytes != 8) return fail(PXL_EINVAL, "sample_plan_create: elem_bytes must be 8 (Float64) or 4 (Float32)");
-    if (nmax < 1 || nmax > 0xffffffffLL) return fail(PXL_EINVAL, "sample_plan_create: nmax must be in [1, 2^32 - 1] (32-bit slots)");
-    pxl_sample_plan* pl = new (std::nothrow) pxl_sample_plan();
-    if (!pl) return fail(PXL_ENOMEM, "sample_plan_create: host allocation failed");
-    pl->w = *wcs_in;
-    pl->nx = shape_in[0]; pl->ny = shape_in[1]; pl->nc = shape_in[2];
-    pl->row0 = src_row0; pl->nrows = src_nrows; pl->nmax = nmax; pl->dtype = elem_bytes;
-    pl->bound_n = -1;
-    pl->periodic = fabs((double)pl->nx * fabs(wcs_in->cdelt[0] * wcs_in->unit) - PXL_TWOPI_D) < 1e-8;
-    hipError_t e = hipGetDevice(&pl->device);
-    if (e != hipSuccess) { delete pl; return fail(PXL_ENODEV, "hipGetDevice: %s", hipGetErrorString(e)); }
-    // tile grid: th rows x tw columns of about tile_kb, at most 16384 tiles (one u32 per tile in LDS, table rows)
-    const int64_t tile_bytes = (int64_t)env_int("PXL_SAMPLE_TILE_KB", 1800) * 1024;
-    const int64_t lds_bytes = (int64_t)env_int("PXL_SAMPLE_LDS_KB", 144) * 1024;      // strip budget of the LDS gather
-    int64_t th = env_int("PXL_SAMPLE_TH", 64);
-    if (th < 1) th = 1;
-    if (th > pl->ny) th = pl->ny;
-    pl->gather = env_int("PXL_SAMPLE_GATHER", 0) ? 1 : 0;
-    pl->rt = env_int("PXL_SAMPLE_RT", 32) <= 16 ? 16 : 32;
-    int64_t tw, TX, TY, sh, pitch, th_tried = 0;
-    for (;;) {
-        tw = tile_bytes / (th * elem_bytes);
-        if (tw < 64) tw = 64;
-        if ((tw + 2) * 2 * elem_bytes > lds_bytes) tw = lds_bytes / (2 * elem_bytes) - 2;    // a one-row strip must fit LDS
-        if (tw > pl->nx) tw = pl->nx;
-        TX = (pl->nx + tw - 1) / tw;
-        tw = (pl->nx + TX - 1) / TX;                  // even tiles
-        const int64_t epl = 16 / elem_bytes;          // elements per 16 bytes
-        tw = (tw + epl - 1) / epl * epl;              // tiles start on 16-byte boundaries (LDS-DMA staging)
-        TX = (pl->nx + tw - 1) / tw;
-        // strips of the LDS gather: sh source rows (+ 1 halo row) of tw + 1 columns, rows padded to whole 1-KiB DMA
-        // pieces; tiles are a whole number of strips
-        pitch = (tw + 1 + 64 * epl - 1) / (64 * epl) * (64 * epl);
-        sh = lds_bytes / (pitch * elem_bytes) - 1;
-        if (sh < 1) sh = 1;
-        if (sh > th) sh = th;
-        if (pl->gather >= 1) th = (th / sh) * sh;
-        if (th > 4096) th = 4096 / sh * sh > 0 ? 4096 / sh * sh : sh;       // 12 bits of row in the packed cell
-        TY = (pl->ny + th - 1) / th;
-        if (TX * TY <= 16384) break;
-        if (th >= pl->ny || th + sh > 4096 || th <= th_tried) {   // cannot grow the tiles any further (rows exhausted, 12-bit row
-                                                                   // field, or rounding to whole strips undid the growth)
-            delete pl;
-            return fail(PXL_EINVAL, "sample_plan_create: a %lld x %lld map needs more than 16384 tiles of at most %lld columns; "
-                                    "use pxl_sample_car_bilinear_* for it", (long long)shape_in[0], (long long)shape_in[1], (long long)tw);
-        }
-        th_tried = th;
-        th += sh;
-        if (th > pl->ny) th = pl->ny;
-    }
-    pl->g.tw = (int32_t)tw; pl->g.th = (int32_t)th; pl->g.TX = (int32_t)TX; pl->g.TY = (int32_t)TY; pl->g.B = (int32_t)((TX * TY + 3) & ~(int64_t)3);   // padded to four: table rows are read four tiles at a time
-    pl->g.inv_tw = 1.0f / (float)tw; pl->g.inv_th = 1.0f / (float)th;
-    pl->pitch = (int)pitch; pl->sh = (int)sh; pl->ns = (int)((th + sh - 1) / sh);
-    pl->dma_ok = (pl->nx % (16 / elem_bytes) == 0) && env_int("PXL_SAMPLE_DMA", 1) != 0;
-    pl->pt = env_int("PXL_SAMPLE_PT", 16);
-    pl->pt = pl->pt <= 8 ? 8 : (pl->pt <= 16 ? 16 : 32);      // chunk of 8, 16 or 32 Ki points (u16 counts)
-    pl->segs = env_int("PXL_SAMPLE_SEGS", 64);
-    if (pl->segs < 1) pl->segs = 1;
-    if (pl->segs > 1024) pl->segs = 1024;
-    pl->vmajor = env_int("PXL_SAMPLE_VMAJOR", 1) ? 1 : 0;
-    pl->trips = env_int("PXL_SAMPLE_TRIPS", 1);
-    if (pl->trips < 1) pl->trips = 1;
-    const int64_t P = (int64_t)pl->pt * PXL_BIN_THREADS;
-    pl->wmax = (nmax + P - 1) / P;
-    const size_t B = (size_t)pl->g.B;
-    pl->items_max = nmax / ((int64_t)pl->rt * PXL_TREG_THREADS) + (int64_t)B + 8;
-    struct { void** p; size_t bytes; } need[] = {
-        {(void**)&pl->rec, (size_t)nmax * 16}, {(void**)&pl->slot, (size_t)nmax * 4},
-        {(void**)&pl->val, (size_t)nmax * (size_t)pl->nc * (size_t)elem_bytes},
-        {(void**)&pl->cnt, (size_t)pl->wmax * B * 2}, {(void**)&pl->off, (size_t)pl->wmax * B * 4},
-        {(void**)&pl->seg, (size_t)pl->segs * B * 4}, {(void**)&pl->start, (B + 4) * 4},
-        {(void**)&pl->wstart, (B + 4) * 4}, {(void**)&pl->item, (size_t)(pl->items_max + 8) * 4}, {&pl->zero_page, 64}};
-    for (auto& q : need) {
-        e = hipMalloc(q.p, q.bytes);
-        if (e != hipSuccess) {
-            *q.p = nullptr;
-            const size_t want = q.bytes;
-            sample_plan_free(pl);
-            return fail(PXL_ENOMEM, "sample_plan_create: hipMalloc(%zu): %s", want, hipGetErrorString(e));
-        }
-        pl->bytes += q.bytes;
-    }
-    e = hipMemset(pl->zero_page, 0, 64);
-    if (e != hipSuccess) { sample_plan_free(pl); return fail(PXL_EHIP, "sample_plan_create: hipMemset: %s", hipGetErrorString(e)); }
-    *out = pl;
-    return PXL_OK;
-}
-
-int64_t pxl_sample_plan_workspace_bytes(const pxl_sample_plan* pl) {
-    if (!pl) { fail(PXL_EINVAL, "sample_plan_workspace_bytes: null plan"); return -1; }
-    return (int64_t)pl->bytes;
-}
-
-int pxl_sample_plan_tiles(const pxl_sample_plan* pl, int32_t* tile_w, int32_t* tile_h, int32_t* ntiles) {
-    if (!pl) return fail(PXL_EINVAL, "sample_plan_tiles: null plan");
-    if (tile_w) *tile_w = pl->g.tw;
-    if (tile_h) *tile_h = pl->g.th;
-    if (ntiles) *ntiles = pl->g.B;
-    return PXL_OK;
-}
-
-int pxl_sample_plan_destroy(pxl_sample_plan* pl) {
-    if (pl) sample_plan_free(pl);
-    return PXL_OK;
-}
-
-}  // extern "C"
-static int sample_plan_bind(pxl_sample_plan* pl, int64_t n, const double* sky, void* stream) {
-    if (!pl) return fail(PXL_EINVAL, "sample_plan_bind: null plan");
-    if (n < 0 || n > pl->nmax) return fail(PXL_EINVAL, "sample_plan_bind: n outside [0, nmax]");
-    if (n > 0 && !sky) return fail(PXL_EINVAL, "sample_plan_bind: null batch");
-    if (((uintptr_t)sky & 15) != 0) return fail(PXL_EINVAL, "sample_plan_bind: 2xN buffer must be 16-byte aligned");
-    pl->bound_n = -1;
-    if (n == 0) { pl->bound_n = 0; return PXL_OK; }
-    hipStream_t st = (hipStream_t)stream;
-    const Sky2Pix s = sky2pix_setup(pl->w, pl->nx, pl->ny, 1, PXL_FORM_RECIP);
-    const BinGrid g = pl->g;
-    const int64_t P = (int64_t)pl->pt * PXL_BIN_THREADS;
-    const int64_t W = (n + P - 1) / P;
-    const int B = g.B;
-    const int64_t NP = pl->vmajor ? 8 * ((W + 7) / 8) : W;
-    const int S = (int)std::min<int64_t>(pl->segs, NP);
-    const int64_t L = (NP + S - 1) / S;
-    const dim3 cgrid((unsigned)W), cblock(PXL_BIN_THREADS);
-    const dim3 sgrid((unsigned)((B / 4 + 255) / 256), (unsigned)S);
-    const int stop = env_int("PXL_SAMPLE_STOP", 5);          // diagnostics: run only the first `stop` stages
-    if (pl->pt == 8)       hipLaunchKernelGGL((k_bin_count<8>), cgrid, cblock, (size_t)B * 4, st, s, g, n, (const double2*)sky, pl->cnt);
-    else if (pl->pt == 16) hipLaunchKernelGGL((k_bin_count<16>), cgrid, cblock, (size_t)B * 4, st, s, g, n, (const double2*)sky, pl->cnt);
-    else                   hipLaunchKernelGGL((k_bin_count<32>), cgrid, cblock, (size_t)B * 4, st, s, g, n, (const double2*)sky, pl->cnt);
-    if (stop < 2) return check_launch("k_bin_count");
-    hipLaunchKernelGGL(k_bin_segsum, sgrid, dim3(256), 0, st, (const uint16_t*)pl->cnt, W, B, L, pl->vmajor, pl->seg);
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, pl->seg, S, B, pl->start);
-    hipLaunchKernelGGL(k_bin_offsets, sgrid, dim3(256), 0, st, (const uint16_t*)pl->cnt, W, B, L, pl->vmajor,
-                       (const uint32_t*)pl->seg, (const uint32_t*)pl->start, pl->off);
-    int rc = check_launch("k_bin_count/scan");
-    if (rc || stop < 3) return rc;
-    if (pl->pt == 8)       hipLaunchKernelGGL((k_bin_scatter<8>), cgrid, cblock, (size_t)B * 4, st, s, g, n, (const double2*)sky,
-                                              (const uint32_t*)pl->off, pl->rec, pl->slot);
-    else if (pl->pt == 16) hipLaunchKernelGGL((k_bin_scatter<16>), cgrid, cblock, (size_t)B * 4, st, s, g, n, (const double2*)sky,
-                                              (const uint32_t*)pl->off, pl->rec, pl->slot);
-    else                   hipLaunchKernelGGL((k_bin_scatter<32>), cgrid, cblock, (size_t)B * 4, st, s, g, n, (const double2*)sky,
-                                              (const uint32_t*)pl->off, pl->rec, pl->slot);
-    rc = check_launch("k_bin_scatter");
-    if (rc == PXL_OK) pl->bound_n = n;
-    return rc;
-}
-
-template <typename T>
-static int sample_plan_sample_bound_t(pxl_sample_plan* pl, const T* src, T* out, void* stream) {
-    if (!pl) return fail(PXL_EINVAL, "sample_plan_sample_bound: null plan");
-    if ((int)sizeof(T) != pl->dtype) return fail(PXL_EINVAL, "sample_plan_sample_bound: plan was created for %d-byte elements", pl->dtype);
-    if (pl->bound_n < 0) return fail(PXL_EINVAL, "sample_plan_sample_bound: no batch is bound (pxl_sample_plan_bind first)");
-    const int64_t n = pl->bound_n;
-    if (n == 0) return PXL_OK;
-    if (!out || (!src && pl->nrows > 0)) return fail(PXL_EINVAL, "sample_plan_sample_bound: null buffer");
-    hipStream_t st = (hipStream_t)stream;
-    const BinGrid g = pl->g;
-    const int B = g.B;
-    const int stop = env_int("PXL_SAMPLE_STOP", 5);
-    int rc = PXL_OK;
-    if (stop < 4) return rc;
-    const int64_t per_block = 256LL * PXL_BIN_SUNR * pl->trips;
-    const int64_t nblk8 = ((n + per_block - 1) / per_block + 7) / 8;
-    const size_t lds = (size_t)(pl->sh + 1) * pl->pitch * sizeof(T);
-    if (pl->gather == 1) {
-        const int R = pl->rt * PXL_TREG_THREADS;
-        hipLaunchKernelGGL(k_bin_items_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)pl->start, B, R, pl->wstart);
-        hipLaunchKernelGGL(k_bin_items_fill, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, (const uint32_t*)pl->wstart, B, pl->item);
-        const int64_t bound = n / R + B;                        // >= sum over tiles of ceil(count / R)
-        const uint32_t nitems8 = (uint32_t)((bound + 7) / 8);
-        const dim3 grid(nitems8 * 8), block(PXL_TREG_THREADS);
-#define PXL_TREG_LAUNCH(RT_, ONEC_, DMA_)                                                                                       \
-        do {                                                                                                                    \
-            HIP_TRY(hipFuncSetAttribute((const void*)k_sample_tile_regs<T, RT_, ONEC_, DMA_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            hipLaunchKernelGGL((k_sample_tile_regs<T, RT_, ONEC_, DMA_>), grid, block, lds, st, src, pl->nx, pl->ny, (int32_t)pl->nc, pl->row0, \
-                               pl->nrows, pl->periodic, n, g, pl->sh, pl->ns, pl->pitch, (const uint32_t*)pl->start,            \
-                               (const uint32_t*)pl->wstart, (const uint32_t*)pl->item, nitems8, (const double2*)pl->rec, (T*)pl->val, \
-                               (const void*)pl->zero_page, env_int("PXL_SAMPLE_DBG", 0));                                       \
-        } while (0)
-        const bool dma = pl->dma_ok && (((uintptr_t)src & 15) == 0);
-        const bool onec = pl->nc == 1;
-        if (pl->rt == 16) {
-            if (dma) { if (onec) PXL_TREG_LAUNCH(16, true, true); else PXL_TREG_LAUNCH(16, false, true); }
-            else     { if (onec) PXL_TREG_LAUNCH(16, true, false); else PXL_TREG_LAUNCH(16, false, false); }
-        } else {
-            if (dma) { if (onec) PXL_TREG_LAUNCH(32, true, true); else PXL_TREG_LAUNCH(32, false, true); }
-            else     { if (onec) PXL_TREG_LAUNCH(32, true, false); else PXL_TREG_LAUNCH(32, false, false); }
-        }
-#undef PXL_TREG_LAUNCH
-    } else {
-        hipLaunchKernelGGL((k_sample_binned<T>), dim3((unsigned)(nblk8 * 8)), dim3(256), 0, st, src, pl->nx, pl->ny, (int32_t)pl->nc,
-                           pl->row0, pl->nrows, pl->periodic, n, (const double2*)pl->rec, (T*)pl->val, nblk8, pl->trips);
-    }
-    if (stop < 5) return check_launch("k_sample gather");
-    hipLaunchKernelGGL((k_bin_unpermute<T>), dim3(stream_grid((n + 3) / 4, 256)), dim3(256), 0, st, n, (int32_t)pl->nc,
-                       (const uint32_t*)pl->slot, (const T*)pl->val, out);
-
-    return check_launch("k_sample_binned");
-}
-
-
-template <typename T>
-static int sample_plan_execute_t(pxl_sample_plan* pl, const T* src, int64_t n, const double* sky, T* out, void* stream) {
-    if (!pl) return fail(PXL_EINVAL, "sample_plan_execute: null plan");
-    if ((int)sizeof(T) != pl->dtype) return fail(PXL_EINVAL, "sample_plan_execute: plan was created for %d-byte elements", pl->dtype);
-    if (n > 0 && (!out || (!src && pl->nrows > 0))) return fail(PXL_EINVAL, "sample_plan_execute: null buffer");
-    int rc = sample_plan_bind(pl, n, sky, stream);
-    if (rc || pl->bound_n < 0) return rc;          // bound_n < 0: a diagnostic stop before the scatter
-    return sample_plan_sample_bound_t<T>(pl, src, out, stream);
-}
-extern "C" {
-int pxl_sample_plan_execute_f64(pxl_sample_plan* plan, const double* src, int64_t n, const double* sky2xN, double* out, void* stream) {
-    return sample_plan_execute_t<double>(plan, src, n, sky2xN, out, stream);
-}
-
-int pxl_sample_plan_execute_f32(pxl_sample_plan* plan, const float* src, int64_t n, const double* sky2xN, float* out, void* stream) {
-    return sample_plan_execute_t<float>(plan, src, n, sky2xN, out, stream);
-}
-
-int pxl_sample_plan_bind(pxl_sample_plan* plan, int64_t n, const double* sky2xN, void* stream) {
-    return sample_plan_bind(plan, n, sky2xN, stream);
-}
-
-int pxl_sample_plan_sample_bound_f64(pxl_sample_plan* plan, const double* src, double* out, void* stream) {
-    return sample_plan_sample_bound_t<double>(plan, src, out, stream);
-}
-
-int pxl_sample_plan_sample_bound_f32(pxl_sample_plan* plan, const float* src, float* out, void* stream) {
-    return sample_plan_sample_bound_t<float>(plan, src, out, stream);
 }
 
 int pxl_fits_decode_f64(const void* raw_be, double* dst, int64_t n, int bitpix, void* stream) {

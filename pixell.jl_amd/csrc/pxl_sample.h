@@ -330,8 +330,11 @@ __global__ __launch_bounds__(256) void k_sample_bilinear(Sky2Pix s, const T* __r
 #pragma unroll
             for (int u = 0; u < PXL_SUNR; ++u) {
                 wide[u] = o00[u] >= 0 && o01[u] >= 0 && o10[u] == o00[u] + 1 && o11[u] == o01[u] + 1;
-                const TT ra = *reinterpret_cast<const TT*>(pl + (wide[u] ? o00[u] : 0));
-                const TT rb = *reinterpret_cast<const TT*>(pl + (wide[u] ? o01[u] : 0));
+                // the other points still issue the load (no branch in front of the gathers), from an address that always
+                // exists: the first coordinate pair of the batch (16 readable bytes whenever n >= 1).  The map itself may
+                // not have two elements to read -- an empty resident window (src == NULL) or a 1 x 1 one
+                const TT ra = *(wide[u] ? reinterpret_cast<const TT*>(pl + o00[u]) : reinterpret_cast<const TT*>(sky));
+                const TT rb = *(wide[u] ? reinterpret_cast<const TT*>(pl + o01[u]) : reinterpret_cast<const TT*>(sky));
                 m00[u] = (double)ra.a; m10[u] = (double)ra.b; m01[u] = (double)rb.a; m11[u] = (double)rb.b;
             }
 #pragma unroll

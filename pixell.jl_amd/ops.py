@@ -435,93 +435,6 @@ class SamplePairs:
         return self
 
 
-class SampleBinned:
-    """Tile-binned scattered sampler (pxl_sample_plan_*): same result as sample_bilinear, bit for bit, for batches
-    dense enough to be worth sorting into map tiles (about 0.1 points per pixel and up on a map larger than L2).
-    The plan owns its workspace (24 + 8 nc bytes per point of `nmax` for a Float64 map)."""
-
-    def __init__(self, m: Enmap, nmax: int, src_rows=None, full_shape=None):
-        data = _dev_map(m.data, "map data")
-        _require_car(m.wcs)
-        self.wcs = m.wcs
-        self.shape = tuple(m.shape if full_shape is None else full_shape)
-        self.nc = data.shape[0] if data.dim() == 3 else 1
-        self.src_rows = (0, self.shape[1]) if src_rows is None else (int(src_rows[0]), int(src_rows[1]))
-        self.dtype, self.device, self.nmax = data.dtype, data.device, int(nmax)
-        self.data = data
-        self._bound = (0, data.device)
-        self._h = _lib.C.c_void_p()
-        lib = _lib.load()
-        with torch.cuda.device(data.device):
-            _lib.check(lib.pxl_sample_plan_create(
-                _wcs_ref(m.wcs), _lib.shape_arr((self.shape[0], self.shape[1], self.nc)), self.src_rows[0], self.src_rows[1],
-                self.nmax, 4 if data.dtype == torch.float32 else 8, _lib.C.byref(self._h)))
-
-    @property
-    def workspace_bytes(self):
-        return int(_lib.load().pxl_sample_plan_workspace_bytes(self._h))
-
-    @property
-    def tiles(self):
-        """(tile width, tile height, number of tiles) of the binning grid."""
-        a, b, c = _lib.C.c_int32(), _lib.C.c_int32(), _lib.C.c_int32()
-        _lib.check(_lib.load().pxl_sample_plan_tiles(self._h, _lib.C.byref(a), _lib.C.byref(b), _lib.C.byref(c)))
-        return a.value, b.value, c.value
-
-    def sample(self, skycoords: torch.Tensor, data: torch.Tensor = None, out: torch.Tensor = None) -> torch.Tensor:
-        """(nc, N) samples of the plan's map (or of `data`, same geometry) at a 2xN batch of (ra, dec)."""
-        sky = _dev_f64(skycoords, "skycoords")
-        data = self.data if data is None else _dev_map(data, "map data")
-        if data.dtype != self.dtype or data.numel() != self.nc * self.src_rows[1] * self.shape[0]:
-            raise ValueError("map data does not match the plan")
-        if out is None:
-            out = torch.empty((self.nc, sky.shape[0]), dtype=self.dtype, device=sky.device)
-        elif out.dtype != self.dtype or out.numel() != self.nc * sky.shape[0] or not out.is_contiguous() or out.device != sky.device:
-            raise ValueError("out must be a contiguous (nc, N) tensor of the map's dtype on the batch's device")
-        lib = _lib.load()
-        fn = lib.pxl_sample_plan_execute_f32 if self.dtype == torch.float32 else lib.pxl_sample_plan_execute_f64
-        with torch.cuda.device(sky.device):
-            _lib.check(fn(self._h, _ptr(data), sky.shape[0], _ptr(sky), _ptr(out), _stream(sky)))
-        self._bound = (sky.shape[0], sky.device)          # execute = bind + sample_bound: the batch stays bound
-        return out
-
-    def bind(self, skycoords: torch.Tensor):
-        """Count and scatter a 2xN batch into the plan's tiles once; sample_bound() then samples it from any map of the
-        plan's geometry (the same pointing against several maps / iterations)."""
-        sky = _dev_f64(skycoords, "skycoords")
-        self._bound = (sky.shape[0], sky.device)
-        with torch.cuda.device(sky.device):
-            _lib.check(_lib.load().pxl_sample_plan_bind(self._h, sky.shape[0], _ptr(sky), _stream(sky)))
-        return self
-
-    def sample_bound(self, data: torch.Tensor = None, out: torch.Tensor = None) -> torch.Tensor:
-        """(nc, N) samples of `data` (default: the plan's map) at the bound batch."""
-        n, dev = self._bound
-        data = self.data if data is None else _dev_map(data, "map data")
-        if data.dtype != self.dtype or data.numel() != self.nc * self.src_rows[1] * self.shape[0]:
-            raise ValueError("map data does not match the plan")
-        if out is None:
-            out = torch.empty((self.nc, n), dtype=self.dtype, device=dev)
-        elif out.dtype != self.dtype or out.numel() != self.nc * n or not out.is_contiguous() or out.device != dev:
-            raise ValueError("out must be a contiguous (nc, N) tensor of the map's dtype on the batch's device")
-        lib = _lib.load()
-        fn = lib.pxl_sample_plan_sample_bound_f32 if self.dtype == torch.float32 else lib.pxl_sample_plan_sample_bound_f64
-        with torch.cuda.device(dev):
-            _lib.check(fn(self._h, _ptr(data), _ptr(out), _stream(out)))
-        return out
-
-    def close(self):
-        if self._h:
-            _lib.load().pxl_sample_plan_destroy(self._h)
-            self._h = _lib.C.c_void_p()
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
-
 def sample_bilinear(m: Enmap, skycoords: torch.Tensor, src_rows=None, full_shape=None, pairs: SamplePairs = None) -> torch.Tensor:
     """Bilinear sample of every component of `m` at a 2xN batch of (ra, dec): fused
     sky2pix!(safe=true) [car_proj.jl:165-193] + 2x2 gather.  Returns a (nc, N) tensor.

@@ -328,25 +328,6 @@ def fuzz_sample(rng):
     pairs = pj.SamplePairs(m, src_rows=(s0, sn), full_shape=(nx, ny, nc))
     got = pj.sample_bilinear(None, d_sky, pairs=pairs).cpu().numpy()
     assert bits_equal(got, expect), ("sample via row pairs", params)
-    # the tile-binned plan with random knobs (tile size down to a few pixels, chunk size, chunk order, both gathers, LDS
-    # budget down to one-row strips), nmax >= n, output between canaries
-    knobs = {"PXL_SAMPLE_TILE_KB": int(rng.choice([1, 2, 8, 64, 1800])), "PXL_SAMPLE_TH": int(rng.choice([1, 2, 7, 16, 64])),
-             "PXL_SAMPLE_PT": int(rng.choice([8, 16, 32])), "PXL_SAMPLE_VMAJOR": int(rng.integers(0, 2)),
-             "PXL_SAMPLE_GATHER": int(rng.integers(0, 2)), "PXL_SAMPLE_LDS_KB": int(rng.choice([1, 4, 32, 144])),
-             "PXL_SAMPLE_RT": int(rng.choice([16, 32])), "PXL_SAMPLE_SEGS": int(rng.choice([1, 3, 64])),
-             "PXL_SAMPLE_DMA": int(rng.integers(0, 2))}
-    for k, v in knobs.items():
-        os.environ[k] = str(v)
-    try:
-        plan = pj.SampleBinned(m, max(1, n + int(rng.integers(0, 50))), src_rows=(s0, sn), full_shape=(nx, ny, nc))
-    finally:
-        for k in knobs:
-            del os.environ[k]
-    out = Guarded((nc, n), torch.float32 if f32 else torch.float64)
-    plan.sample(d_sky, out=out.t)
-    got = out.t.cpu().numpy()
-    plan.close()
-    assert bits_equal(got, expect) and out.canaries_intact(), ("sample via the tile-binned plan", params, knobs, plan.tiles if False else None)
     return "sample_f32" if f32 else "sample_f64"
 
 

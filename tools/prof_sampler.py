@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """cfg5 under the profiler: N uniform-on-sphere points sampled from the 43200x21601 Float64 map, a few launches of
-each sampler variant (PXL_MODES = comma list of direct,pairs,binned).  Prints one JSON line per variant with the
+each sampler variant (PXL_MODES = comma list of direct,pairs).  Prints one JSON line per variant with the
 HIP-event median; run it directly after `rocprofv3 ... --` (tools/collect_cfg5.sh)."""
 import json, math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -36,10 +36,6 @@ for mode in modes:
         pairs = pj.SamplePairs(m)
         ms = t(lambda: pj.sample_bilinear(None, sky, pairs=pairs))
         del pairs
-    elif mode == "binned":
-        plan = pj.SampleBinned(m, n)
-        ms = t(lambda: plan.sample(sky))
-        del plan
     else:
         raise SystemExit("unknown mode " + mode)
     print(json.dumps({"mode": mode, "n": n, "ms": round(ms, 3), "Gpts/s": round(n / ms / 1e6, 2),
