@@ -484,9 +484,11 @@ int pxl_sky2pix_tan_f64(const pxl_car_wcs* wcs, int64_t n, const double* ra, con
     if (!wcs_ok(wcs)) return fail(PXL_EINVAL, "sky2pix_tan: invalid WCS");
     if (n < 0 || (n > 0 && (!ipix || !jpix || !ra || !dec))) return fail(PXL_EINVAL, "sky2pix_tan: null buffer or negative n");
     if (n == 0) return PXL_OK;
-    hipLaunchKernelGGL(k_sky2pix_tan, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       tan_setup(*wcs), n, ra, dec, ipix, jpix);
-    return check_launch("k_sky2pix_tan");
+    const bool vec = ((((uintptr_t)ra | (uintptr_t)dec | (uintptr_t)ipix | (uintptr_t)jpix) & 15) == 0);
+    const dim3 grid(stream_grid((n + 1) / 2, 256));
+    if (vec) hipLaunchKernelGGL((k_tan_points<true, false>), grid, dim3(256), 0, (hipStream_t)stream, tan_setup(*wcs), n, ra, dec, ipix, jpix);
+    else     hipLaunchKernelGGL((k_tan_points<false, false>), grid, dim3(256), 0, (hipStream_t)stream, tan_setup(*wcs), n, ra, dec, ipix, jpix);
+    return check_launch("k_tan_points (sky2pix)");
 }
 
 int pxl_pix2sky_tan_f64(const pxl_car_wcs* wcs, int64_t n, const double* ipix, const double* jpix, double* ra,
@@ -494,9 +496,11 @@ int pxl_pix2sky_tan_f64(const pxl_car_wcs* wcs, int64_t n, const double* ipix, c
     if (!wcs_ok(wcs)) return fail(PXL_EINVAL, "pix2sky_tan: invalid WCS");
     if (n < 0 || (n > 0 && (!ipix || !jpix || !ra || !dec))) return fail(PXL_EINVAL, "pix2sky_tan: null buffer or negative n");
     if (n == 0) return PXL_OK;
-    hipLaunchKernelGGL(k_pix2sky_tan, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       tan_setup(*wcs), n, ipix, jpix, ra, dec);
-    return check_launch("k_pix2sky_tan");
+    const bool vec = ((((uintptr_t)ra | (uintptr_t)dec | (uintptr_t)ipix | (uintptr_t)jpix) & 15) == 0);
+    const dim3 grid(stream_grid((n + 1) / 2, 256));
+    if (vec) hipLaunchKernelGGL((k_tan_points<true, true>), grid, dim3(256), 0, (hipStream_t)stream, tan_setup(*wcs), n, ipix, jpix, ra, dec);
+    else     hipLaunchKernelGGL((k_tan_points<false, true>), grid, dim3(256), 0, (hipStream_t)stream, tan_setup(*wcs), n, ipix, jpix, ra, dec);
+    return check_launch("k_tan_points (pix2sky)");
 }
 
 int pxl_posmap_tan_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64_t row0, int64_t nrows, double* ra,
@@ -506,8 +510,12 @@ int pxl_posmap_tan_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64_t r
     if (rc) return rc;
     if (nrows == 0) return PXL_OK;
     if (!ra || !dec) return fail(PXL_EINVAL, "posmap_tan: null output");
-    hipLaunchKernelGGL(k_posmap_tan, dim3(stream_grid(shape[0] * nrows, 256)), dim3(256), 0,
-                       (hipStream_t)stream, tan_setup(*wcs), shape[0], row0, nrows, ra, dec);
+    const int64_t nchunk = (shape[0] + 511) / 512;                 // 512 RA pixels per block
+    if (nchunk * nrows > 0x7fffffffLL) return fail(PXL_EINVAL, "posmap_tan: map too large for one launch");
+    const bool vec = (shape[0] % 2 == 0) && ((((uintptr_t)ra | (uintptr_t)dec) & 15) == 0);
+    const dim3 grid((unsigned)(nchunk * nrows));
+    if (vec) hipLaunchKernelGGL((k_posmap_tan<true>), grid, dim3(256), 0, (hipStream_t)stream, tan_setup(*wcs), shape[0], row0, nrows, nchunk, ra, dec);
+    else     hipLaunchKernelGGL((k_posmap_tan<false>), grid, dim3(256), 0, (hipStream_t)stream, tan_setup(*wcs), shape[0], row0, nrows, nchunk, ra, dec);
     return check_launch("k_posmap_tan");
 }
 

@@ -4,7 +4,24 @@
 // ------------------------------------------------------------------------------------------------
 // Gnomonic (A16), tan_proj.jl:44-75
 // ------------------------------------------------------------------------------------------------
-struct TanParams { double scale, unit, a0, d0, sd0, cd0, cpx, cpy; };
+// These are tolerance-checked paths (FP64 transcendentals: device libm vs glibc), held to the reference's own bar for
+// its fast Gnomonic code against wcslib: sum |difference| < 1e-9 over the 1827 x 1825 posmap (test_geometry.jl:116-119).
+//
+// sky2pix keeps the reference's operations one for one; each angle's sine and cosine come from ONE sincos (one
+// argument reduction instead of two) and the loop-invariant scale / unit is divided once on the host (a correctly
+// rounded quotient either way).
+//
+// pix2sky is evaluated in an algebraically equal form without the intermediate angles.  The reference
+// (tan_proj.jl:59-75) forms D = atan(r), B = atan(-X, Y) and then only ever uses sin D, cos D, sin B, cos B:
+//      sin D = r / s,  cos D = 1 / s,  cos B = Y / r,  sin B = -X / r        (r = hypot(X, Y), s = sqrt(1 + r^2))
+//      XX = sin d0 sinD cosB + cos d0 cosD = (sin d0 Y + cos d0) / s
+//      YY = sinD sinB                      = -X / s
+//      alpha = a0 + atan(YY, XX)           = a0 + atan(-X, sin d0 Y + cos d0)          (s > 0 cancels)
+//      delta = asin(sin d0 cosD - cos d0 sinD cosB) = asin((sin d0 - cos d0 Y) / s)
+// i.e. one rsqrt, one atan2 and one asin instead of sqrt, atan, two atan2, two sin, two cos and asin.  On the
+// reference's patch the two forms differ by at most one ulp of the angle, 3e-11 (RA) / 6e-11 (DEC) summed over the
+// 3.3 M pixels against the 1e-9 allowed (glibc on both sides; tests/test_gpu_parity.py holds the device to the bound).
+struct TanParams { double scale, unit, a0, d0, sd0, cd0, cpx, cpy, su; };
 static TanParams tan_setup(const pxl_car_wcs& w) {
     TanParams t;
     t.scale = 1.0 / w.cdelt[0];
@@ -13,47 +30,90 @@ static TanParams tan_setup(const pxl_car_wcs& w) {
     t.d0 = w.crval[1] * (PXL_PI_D / 180);
     t.sd0 = sin(t.d0); t.cd0 = cos(t.d0);
     t.cpx = w.crpix[0]; t.cpy = w.crpix[1];
+    t.su = t.scale / t.unit;                 // the left-to-right head of `scale / unit / (...)`, tan_proj.jl:50
     return t;
 }
 __device__ inline void tan_sky2pix(const TanParams& t, double a, double d, double* x, double* y) {
-    double A = cos(d) * cos(a - t.a0);
-    double F = t.scale / t.unit / (t.sd0 * sin(d) + A * t.cd0);
-    double LINE = -F * (t.cd0 * sin(d) - A * t.sd0);
-    double SAMPLE = -F * cos(d) * sin(a - t.a0);
+    double sd, cd, sa, ca;
+    sincos(d, &sd, &cd);
+    sincos(a - t.a0, &sa, &ca);
+    double A = cd * ca;
+    double F = t.su / (t.sd0 * sd + A * t.cd0);
+    double LINE = -F * (t.cd0 * sd - A * t.sd0);
+    double SAMPLE = -F * cd * sa;
     *x = t.cpx - SAMPLE;
     *y = t.cpy - LINE;
 }
+// the row-dependent half of pix2sky: Y and the two combinations of it that every pixel of a row shares
+struct TanRow { double Y2, den, num; };
+__device__ inline TanRow tan_row(const TanParams& t, double j) {
+    const double Y = (t.cpy - j) * t.unit / t.scale;
+    return TanRow{Y * Y, t.sd0 * Y + t.cd0, t.sd0 - t.cd0 * Y};
+}
+__device__ inline void tan_pix2sky_row(const TanParams& t, const TanRow& r, double i, double* a, double* d) {
+    const double X = (t.cpx - i) * t.unit / t.scale;
+    const double rs = rsqrt(1.0 + (X * X + r.Y2));
+    *a = t.a0 + atan2(-X, r.den);
+    *d = asin(r.num * rs);
+}
 __device__ inline void tan_pix2sky(const TanParams& t, double i, double j, double* a, double* d) {
-    double X = (t.cpx - i) * t.unit / t.scale;
-    double Y = (t.cpy - j) * t.unit / t.scale;
-    double D = atan(sqrt(X * X + Y * Y));
-    double B = atan2(-X, Y);
-    double sD = sin(D), cD = cos(D), cB = cos(B);
-    double XX = t.sd0 * sD * cB + t.cd0 * cD;
-    double YY = sD * sin(B);
-    *a = t.a0 + atan2(YY, XX);
-    *d = asin(t.sd0 * cD - t.cd0 * sD * cB);
+    tan_pix2sky_row(t, tan_row(t, j), i, a, d);
 }
-__global__ __launch_bounds__(256) void k_sky2pix_tan(TanParams t, int64_t n, const double* __restrict__ ra,
-                                                     const double* __restrict__ dec, double* __restrict__ x,
-                                                     double* __restrict__ y) {
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride)
-        tan_sky2pix(t, ra[k], dec[k], &x[k], &y[k]);
+
+// Two points per lane, 16-byte accesses (VEC: all four arrays 16-byte aligned), one contiguous chunk per block.
+template <bool VEC, bool INVERSE>
+__global__ __launch_bounds__(256) void k_tan_points(TanParams t, int64_t n, const double* __restrict__ in1,
+                                                    const double* __restrict__ in2, double* __restrict__ out1,
+                                                    double* __restrict__ out2) {
+    const int64_t npair = (n + 1) / 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npair; p += stride) {
+        const int64_t k = 2 * p;
+        const bool two = k + 1 < n;
+        double u[2], v[2], r[2], s[2];
+        if (VEC && two) {
+            const double2 a = *reinterpret_cast<const double2*>(in1 + k), b = *reinterpret_cast<const double2*>(in2 + k);
+            u[0] = a.x; u[1] = a.y; v[0] = b.x; v[1] = b.y;
+        } else {
+            u[0] = in1[k]; v[0] = in2[k];
+            u[1] = two ? in1[k + 1] : u[0]; v[1] = two ? in2[k + 1] : v[0];
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (INVERSE) tan_pix2sky(t, u[e], v[e], &r[e], &s[e]);      // (i, j) -> (ra, dec)
+            else         tan_sky2pix(t, u[e], v[e], &r[e], &s[e]);      // (ra, dec) -> (x, y)
+        }
+        if (VEC && two) {
+            *reinterpret_cast<double2*>(out1 + k) = make_double2(r[0], r[1]);
+            *reinterpret_cast<double2*>(out2 + k) = make_double2(s[0], s[1]);
+        } else {
+            out1[k] = r[0]; out2[k] = s[0];
+            if (two) { out1[k + 1] = r[1]; out2[k + 1] = s[1]; }
+        }
+    }
 }
-__global__ __launch_bounds__(256) void k_pix2sky_tan(TanParams t, int64_t n, const double* __restrict__ ip,
-                                                     const double* __restrict__ jp, double* __restrict__ ra,
-                                                     double* __restrict__ dec) {
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride)
-        tan_pix2sky(t, ip[k], jp[k], &ra[k], &dec[k]);
-}
-__global__ __launch_bounds__(256) void k_posmap_tan(TanParams t, int64_t nx, int64_t row0, int64_t nrows,
+
+// posmap of a Gnomonic map: a block covers 512 adjacent RA pixels of one row (two per lane, 16-byte stores when the
+// row pitch allows); the row's share of the arithmetic is computed once per lane.
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_posmap_tan(TanParams t, int64_t nx, int64_t row0, int64_t nrows, int64_t nchunk,
                                                     double* __restrict__ ra, double* __restrict__ dec) {
-    const int64_t total = nx * nrows;
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += stride) {
-        int64_t jr = k / nx, i = k - jr * nx;
-        tan_pix2sky(t, (double)(i + 1), (double)(row0 + jr + 1), &ra[k], &dec[k]);
+    const int64_t b = blockIdx.x;
+    const int64_t jr = b / nchunk;
+    if (jr >= nrows) return;
+    const int64_t i = ((b - jr * nchunk) * blockDim.x + threadIdx.x) * 2;      // 0-based column of the lane's first pixel
+    if (i >= nx) return;
+    const TanRow r = tan_row(t, (double)(row0 + jr + 1));
+    double a[2], d[2];
+    const bool two = i + 1 < nx;
+    tan_pix2sky_row(t, r, (double)(i + 1), &a[0], &d[0]);
+    if (two) tan_pix2sky_row(t, r, (double)(i + 2), &a[1], &d[1]);
+    const int64_t o = jr * nx + i;
+    if (VEC && two) {
+        *reinterpret_cast<double2*>(ra + o) = make_double2(a[0], a[1]);
+        *reinterpret_cast<double2*>(dec + o) = make_double2(d[0], d[1]);
+    } else {
+        ra[o] = a[0]; dec[o] = d[0];
+        if (two) { ra[o + 1] = a[1]; dec[o + 1] = d[1]; }
     }
 }
