@@ -405,6 +405,9 @@ def bench_reproject(args, rank, world, dev):
             sys.exit("bench.py: no halo transport worked (a host-staged gloo run is not an N-GPU result; ask for it by "
                      "name with --halo gloo): " + "; ".join(notes))
         halo = chosen
+        if own_comm is not None and chosen != "native_own_comm":
+            sh.close_own_comm()                          # made during a pre-flight, not the transport that runs
+            own_comm = None
         if chosen == "gloo" and ctrl is not None:
             _CTRL = ctrl                                 # the harness collectives move to the host as well
         transport = {"native": "RCCL send/recv issued by pxl_reproject_sharded_step over torch's communicator (no staging)",
@@ -508,6 +511,9 @@ def bench_reproject(args, rank, world, dev):
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_CTRL)
             chk = {"max_abs_err": float(t[0]), "bit_identical": bool(t[1] == 0.0), "ranks_checked": world}
         result["check"] = chk
+    if own_comm is not None:
+        torch.cuda.synchronize(dev)
+        sh.close_own_comm()
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         del src, dst
         torch.cuda.empty_cache()

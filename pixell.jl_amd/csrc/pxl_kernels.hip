@@ -934,8 +934,12 @@ int pxl_comm_destroy(void* comm) {
 }
 
 const char* pxl_comm_backend(void) {
-    const RcclApi& nc = rccl_api(false);
-    return nc.where;
+    // a diagnostic: it probes for an instance already in the process but latches nothing (pxl_rccl.h); the text lives in
+    // a thread-local buffer, valid until this thread asks again
+    static thread_local char where[256];
+    const RcclApi nc = rccl_api(false);
+    snprintf(where, sizeof where, "%s", nc.where);
+    return where;
 }
 
 int pxl_reproject_sharded_step_f64(pxl_reproject_plan* plan, double* src, double* dst, int64_t own_row0, int64_t own_nrows,

@@ -48,15 +48,17 @@ static void rccl_resolve(RcclApi& a, void* h) {
 
 static std::mutex g_rccl_mu;
 static RcclApi g_rccl = {};
-static bool g_rccl_tried_present = false, g_rccl_tried_own = false;
+static bool g_rccl_tried_own = false;
 static std::set<void*> g_own_comms;
 
-// allow_own: the caller is about to CREATE a communicator, so loading an instance of our own is legitimate
-static const RcclApi& rccl_api(bool allow_own) {
+// allow_own: the caller is about to CREATE a communicator, so loading an instance of our own is legitimate.
+// Returns a COPY taken under the lock (the table is frozen once ok; until then a later call may still fill it in).
+// A negative probe for an instance already in the process is NOT remembered: it is one cheap dlopen(RTLD_NOLOAD),
+// and a host may load its RCCL after an early diagnostic call (pxl_comm_backend) or a step issued too soon.
+static RcclApi rccl_api(bool allow_own) {
     std::lock_guard<std::mutex> lock(g_rccl_mu);
     if (g_rccl.ok) return g_rccl;
-    if (!g_rccl_tried_present) {
-        g_rccl_tried_present = true;
+    {
         const char* env = getenv("PXL_RCCL_LIB");
         void* h = nullptr;
         if (env && *env) {                                   // explicit: the host says which instance is its own

@@ -231,6 +231,10 @@ def _resolve_polcconv(h, out, comps, verbose, mode="reference"):
         if verbose:
             print("convert to IAU: flip U in axis %d" % i)
         flip = (0, 2) if mode == "reference" else (2,)
+        if mode == "reference" and 0 in comps:
+            import warnings
+            warnings.warn("POLCCONV=IAU: following the reference (enmap.jl:186-187, `signs[signs_size] .= -1` is a linear "
+                          "index), Stokes I is negated as well as U; pass polcconv='u_only' to flip U alone", stacklevel=3)
         for plane, c in enumerate(comps):
             if c in flip:
                 out[plane].neg_()

@@ -228,12 +228,21 @@ class DecStripReprojector(DecStripLayout):
         from . import _lib
         lib = _lib.load()
         ident = C.create_string_buffer(128)
+        # rank 0 ALWAYS broadcasts -- the id or the reason it could not make one -- so that a failure there (RCCL not
+        # found, a bad PXL_RCCL_LIB) reaches every rank as an exception instead of leaving them in the broadcast
+        box = [None]
         if self.rank == 0:
-            with torch.cuda.device(self.device):
-                _lib.check(lib.pxl_comm_unique_id(ident))
-        box = [bytes(ident.raw)]
+            try:
+                with torch.cuda.device(self.device):
+                    _lib.check(lib.pxl_comm_unique_id(ident))
+                box = [(True, bytes(ident.raw))]
+            except Exception as e:                  # noqa: BLE001 -- re-raised on every rank below
+                box = [(False, "%s: %s" % (type(e).__name__, (str(e).splitlines() or [""])[0][:200]))]
         dist.broadcast_object_list(box, src=0, group=ctrl_group)
-        ident = C.create_string_buffer(box[0], 128)
+        ok, payload = box[0]
+        if not ok:
+            raise RuntimeError("rank 0 could not create the communicator id: " + payload)
+        ident = C.create_string_buffer(payload, 128)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(lib.pxl_comm_init_rank(ident, self.rank, self.world, C.byref(h)))

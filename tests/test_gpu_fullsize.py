@@ -111,29 +111,35 @@ def test_config1_roundtrip_and_posmap_fullsize(pj, dev):
 
 
 def test_config5_scattered_sample_properties(pj, O, dev):
-    """1e7 uniform-on-sphere points from the 0.5-arcmin map: a seeded subset against the oracle, sample of a
-    constant map is that constant, sample of the DEC-row-index map reproduces y - (not wrapped)."""
+    """1.25e8 uniform-on-sphere points (config 5's share of one of 8 GPUs: a 2 GB coordinate batch) from the
+    0.5-arcmin map: seeded subsets from both ends of the batch against the oracle through BOTH samplers (direct
+    gather and row-pair copy), all points equal between the two, sample of a constant map is that constant."""
     shape, wcs = pj.fullsky_geometry(2 * math.pi / 43200)
     nx, ny = shape
     m = pj.Enmap(torch.empty((ny, nx), dtype=torch.float64, device=dev), wcs)
     pj.fill_random_(m.data, 1234)
-    n = 10_000_000
+    n = 125_000_000
     sky = torch.empty((n, 2), dtype=torch.float64, device=dev)
     pj.fill_sphere_points_(sky, 42)
     out = pj.sample_bilinear(m, sky)
     assert bool(torch.isfinite(out).all())
-    # subset vs oracle: the oracle only needs the rows those points touch -> take points in a DEC band
-    pix = pj.sky2pix(m, sky[:200000], safe=True)
-    band = (pix[:, 1] >= 12000) & (pix[:, 1] < 12040)
-    idx = torch.nonzero(band).reshape(-1)
-    assert idx.numel() > 100
-    rows = m.data[11999:12041].cpu().numpy()[None]
-    exp = O.sample_bilinear(wcs, (nx, ny, 1), rows, sky[idx].cpu().numpy(), src_row0=11999, src_nrows=42)
-    assert bits_equal(out[:, idx].cpu().numpy(), exp)
-    # the row-pair copy of the same map (15 GB: offsets beyond 2^31 bytes) gives the same bits for every point
+    # the row-pair copy of the same map (20 GB: offsets beyond 2^31 bytes) gives the same bits for every point
     pairs = pj.SamplePairs(m)
-    assert torch.equal(pj.sample_bilinear(None, sky, pairs=pairs), out)
+    out_pairs = pj.sample_bilinear(None, sky, pairs=pairs)
+    assert torch.equal(out_pairs, out)
     del pairs
+    # subsets vs oracle: the oracle only needs the rows those points touch -> take points in a DEC band, from the first
+    # and the last 200 000 points of the batch (the tail sits beyond 2^31 bytes of the coordinate buffer)
+    rows = m.data[11999:12041].cpu().numpy()[None]
+    for lo in (0, n - 200000):
+        pix = pj.sky2pix(m, sky[lo:lo + 200000], safe=True)
+        band = (pix[:, 1] >= 12000) & (pix[:, 1] < 12040)
+        idx = torch.nonzero(band).reshape(-1) + lo
+        assert idx.numel() > 100
+        exp = O.sample_bilinear(wcs, (nx, ny, 1), rows, sky[idx].cpu().numpy(), src_row0=11999, src_nrows=42)
+        assert bits_equal(out[:, idx].cpu().numpy(), exp)
+        assert bits_equal(out_pairs[:, idx].cpu().numpy(), exp)
+    del out_pairs
     m.data.fill_(3.25)
     assert float((pj.sample_bilinear(m, sky) - 3.25).abs().max()) < 1e-12
 
