@@ -153,7 +153,11 @@ def place_buffers(sh, candidates, dev, keep="first", arena=False):
     ballast = []
     holds = []
     for k in range(max(1, candidates)):
-        if arena:       # one allocation, destination above the source (sharding.alloc_pair: a fixed policy, nothing probed)
+        if arena == "placed":   # one allocation with head-room, its memory classes mapped with the library's store probe, the
+            # destination put across a class boundary (pixell.jl_amd/placement.py): topology discovery, no timing of this workload
+            src, dst, pinfo = pj.place_pair(sh.src_tensor_shape(), sh.dst_tensor_shape(), device=dev)
+            holds.append(pinfo.pop("arena"))
+        elif arena:       # one allocation, destination above the source (sharding.alloc_pair: a fixed policy, nothing probed)
             src, dst, hold = sh.alloc_pair()
             holds.append(hold)
         else:
@@ -175,7 +179,8 @@ def place_buffers(sh, candidates, dev, keep="first", arena=False):
         if best is None or (keep == "best" and t < best[2]):
             best = (src, dst, t)
         del src, dst
-        holds.clear()
+        if arena != "placed":
+            holds.clear()
         if k + 1 < candidates:
             # return the losing blocks to the driver and perturb the heap so the next try lands elsewhere
             ballast.append(torch.empty(int(rng.uniform(0.3, 3.0) * 2**30), dtype=torch.uint8, device=dev))
@@ -184,7 +189,10 @@ def place_buffers(sh, candidates, dev, keep="first", arena=False):
             torch.cuda.empty_cache()
     del ballast
     torch.cuda.empty_cache()
-    return best[0], best[1], {"allocation": "one allocation, destination above the source (DecStripReprojector.alloc_pair: fixed policy, nothing probed)" if arena else "two allocations", "candidates_ms": tried,
+    alloc_desc = ("one allocation, destination above the source (DecStripReprojector.alloc_pair: fixed policy, nothing probed)" if arena else "two allocations")
+    if arena == "placed":
+        alloc_desc = {"policy": "pj.place_pair: one allocation with head-room, memory classes mapped with pxl_mem_probe_pair, destination across a class boundary", **pinfo}
+    return best[0], best[1], {"allocation": alloc_desc, "candidates_ms": tried,
                               "chosen_ms": round(best[2], 4), "chosen": keep,
                               "first_ms": tried[0], "median_ms": sorted(tried)[len(tried) // 2], "best_ms": min(tried)}
 
@@ -219,6 +227,10 @@ def main():
                          "20 of 24 processes on 9 boxes, two separate allocations in about half")
     ap.add_argument("--two-allocations", dest="arena", action="store_false",
                     help="allocate the source and the destination separately (round 1's and early round 2's default)")
+    ap.add_argument("--placed", dest="arena", action="store_const", const="placed",
+                    help="class-aware placement (pj.place_pair): the destination across a boundary between two of the HBM's three "
+                         "memory classes, found with the library's store probe (DESIGN 9 item 6).  N = 1 only.  The default run reports "
+                         "it beside the plain first placement for cfg4 / cfg3 / cfg3s (configs block) without making it the headline")
     ap.add_argument("--keep-placement", default="first", choices=["first", "best"],
                     help="which probed placement the timed steps run on (first = unselected headline)")
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the output of the timed run is always "
@@ -335,7 +347,9 @@ def bench_reproject(args, rank, world, dev):
     nx, ny, nc = shape_in
     nxo, nyo = shape_out
     sh = pj.DecStripReprojector(shape_in, wcs_in, shape_out, wcs_out, rank, world, dev)
-    src, dst, placement = place_buffers(sh, args.placements, dev, args.keep_placement, arena=args.arena)
+    if args.arena == "placed" and world > 1:
+        sys.exit("bench.py --placed is a one-GPU option")
+    src, dst, placement = place_buffers(sh, 1 if args.arena == "placed" else args.placements, dev, args.keep_placement, arena=args.arena)
     torch.cuda.synchronize(dev)
     # ---- choose the halo transport (N > 1).  Candidates in order: "native" = the library's own sharded step (RCCL
     # send/recv issued from C straight out of / into the resident buffer), "torch" = torch.distributed
@@ -679,6 +693,13 @@ def side_measurements(args, dev, result):
                       "traffic": r["roofline"]["traffic"], "steps": a.steps, "check": r["check"]}
         if name == "cfg2":
             cfgs[name]["note"] = "268 MB of output: Infinity-Cache resident, not roofline evidence (SURVEY 8(d))"
+        else:
+            cfgs[name]["class_aware_placement"] = placed_variant(a, dev)
+    a = argparse.Namespace(**vars(args))
+    a.workload, a.steps, a.warmup, a.sustain_seconds, a.no_cpu_baseline, a.placements = "cfg4", 10, 2, 0.0, True, 1
+    cfgs["cfg4"] = {"workload": result["config"]["workload"], "ms_per_step": result["ms_per_step"], "kernel_ms_avg": result["roofline"]["kernel_ms_avg"],
+                    "frac": result["roofline"]["frac"], "note": "the headline above (plain first placement)",
+                    "class_aware_placement": placed_variant(a, dev)}
     a = argparse.Namespace(**vars(args))
     a.workload, a.steps, a.warmup = "cfg5", 6, 2
     torch.cuda.empty_cache()
@@ -692,6 +713,22 @@ def side_measurements(args, dev, result):
     torch.cuda.empty_cache()
     if "cpu_baseline" in result:
         result["cpu_baseline"].update(cpu_baseline_evaluators())
+
+
+def placed_variant(a, dev):
+    """The same workload with its maps placed by pj.place_pair (destination across a boundary between two memory classes)."""
+    a = argparse.Namespace(**vars(a))
+    a.arena = "placed"
+    torch.cuda.empty_cache()
+    r = bench_reproject(a, 0, 1, dev)
+    torch.cuda.empty_cache()
+    al = r["config"]["buffer_placement"]["allocation"]
+    return {"Mpix_s": r["value"], "ms_per_step": r["ms_per_step"], "kernel_ms_avg": r["roofline"]["kernel_ms_avg"], "frac": r["roofline"]["frac"],
+            "check": r["check"], "placement": al["placement"], "allocation_GiB": al["allocation_GiB"], "classes": al["classes"],
+            "class_runs_label_from_to_GiB": al["class_runs_label_from_to_GiB"], "probe_us_same_class": al["probe_us_same_class"],
+            "probe_us_different_classes": al["probe_us_different_classes"],
+            "note": "pj.place_pair: topology discovery with the library's store probe, nothing about this workload is timed or selected; "
+                    "not the headline"}
 
 
 def _median_ms(fn, dev, reps=7):

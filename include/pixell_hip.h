@@ -261,6 +261,16 @@ int pxl_fits_encode_f64(const double* src, void* raw_be, int64_t n, void* stream
 /* BITPIX -32 <-> native Float32 (the 4-byte swap is its own inverse; in place allowed) */
 int pxl_fits_swap_f32(const void* src, void* dst, int64_t n, void* stream);
 
+/* ---- Placement probe.  The memory of a hipMalloc'ed allocation on the MI355X falls into three classes (thirds of the 288 GiB:
+ *      DESIGN.md 9, profiles/r03_xcd_classes.txt): a kernel with several far-apart WRITE fronts -- the reprojection keeps one
+ *      per XCD -- stores at 5.8-6.0 TB/s when all of them lie in one class and at 6.8-7.1 TB/s when they are split over two.
+ *      This entry times the pattern that defines the classes: eight store fronts (one per XCD), four in window a and four in
+ *      window b, each writing window_bytes / 4 bytes of ZEROS (both windows are overwritten).  `us` receives the median of
+ *      `reps` launches in microseconds; with 1 GiB windows about 380 us = same class, 305 us = different classes.  It
+ *      synchronises `stream`.  A host can map an allocation with it and put a destination across a class boundary
+ *      (pixell.jl_amd/placement.py); nothing in the library calls it.  No reference counterpart.                        */
+int pxl_mem_probe_pair(void* a, void* b, size_t window_bytes, int reps, float* us, void* stream);
+
 /* ---- synthetic inputs (benchmark plumbing, deterministic counter-based generator):
  *      fill n doubles with N(0,1) (kind 0) or U[0,1) (kind 1) from splitmix64(seed, index+offset);
  *      uniform-on-sphere points (ra = 2pi*u1 - pi, dec = asin(2*u2 - 1)) as a 2xN batch.             */

@@ -77,6 +77,7 @@ SIGNATURES = {
     "pxl_fits_decode_f64": (C.c_int, [_P, _P, _I64, C.c_int, _P]),
     "pxl_fits_encode_f64": (C.c_int, [_P, _P, _I64, _P]),
     "pxl_fits_swap_f32": (C.c_int, [_P, _P, _I64, _P]),
+    "pxl_mem_probe_pair": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_float), _P]),
     "pxl_fill_random_f64": (C.c_int, [_P, _I64, C.c_uint64, C.c_uint64, C.c_int, _P]),
     "pxl_fill_sphere_points_f64": (C.c_int, [_P, _I64, C.c_uint64, C.c_uint64, _P]),
 }

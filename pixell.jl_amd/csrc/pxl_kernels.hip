@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <vector>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -84,6 +85,7 @@ static int env_int(const char* name, int dflt) {
 #include "pxl_sample.h"
 #include "pxl_misc.h"
 #include "pxl_rccl.h"
+#include "pxl_spread.h"
 
 // ================================================================================================
 // C ABI
@@ -279,6 +281,36 @@ int pxl_release_scratch(void) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(PXL_ENODEV, "release_scratch: no current device");
     std::lock_guard<std::mutex> lock(g_pool_mu);
     if (g_pools[dev] && hipMemPoolTrimTo(g_pools[dev], 0) != hipSuccess) return fail(PXL_EHIP, "release_scratch: hipMemPoolTrimTo failed");
+    return PXL_OK;
+}
+
+// ---- placement probe (pxl_spread.h): eight store fronts, four in each of two windows
+int pxl_mem_probe_pair(void* a, void* b, size_t window_bytes, int reps, float* us, void* stream) {
+    if (!a || !b || !us) return fail(PXL_EINVAL, "mem_probe_pair: null argument");
+    if (window_bytes < (64u << 20) || (window_bytes & 63) != 0 || (((uintptr_t)a | (uintptr_t)b) & 15) != 0)
+        return fail(PXL_EINVAL, "mem_probe_pair: windows of at least 64 MiB, a multiple of 64 bytes, 16-byte aligned");
+    if (reps < 1 || reps > 99) return fail(PXL_EINVAL, "mem_probe_pair: 1..99 repetitions");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    std::vector<float> t(reps);
+    int rc = PXL_OK;
+    for (int r = -1; r < reps && rc == PXL_OK; ++r) {
+        hipError_t e = hipEventRecord(e0, st);
+        hipLaunchKernelGGL(k_spread_probe, dim3(8 * 256 * 2), dim3(256), 0, st, (char*)a, (char*)b, window_bytes / 4);
+        if (e == hipSuccess) e = hipEventRecord(e1, st);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) rc = fail(PXL_EHIP, "mem_probe_pair: %s", hipGetErrorString(e));
+        else if (r >= 0) t[r] = ms * 1000.f;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    std::sort(t.begin(), t.end());
+    *us = t[reps / 2];
     return PXL_OK;
 }
 

@@ -1,0 +1,147 @@
+"""Class-aware placement of a (source, destination) pair of maps in MI355X HBM.
+
+Round 3 found why the same reprojection ran 10-17 % faster with its destination "in some places" (DESIGN.md 9, item 6;
+profiles/r03_xcd_classes.txt, r03_scan_placement_*.jsonl): the memory of a hipMalloc'ed allocation falls into three classes
+(thirds of the 288 GiB), and a kernel with several far-apart WRITE fronts -- the reprojection keeps one per XCD -- stores at
+5.8-6.0 TB/s when all fronts lie in one class and at 6.8-7.1 TB/s when they are split over two.  A plain allocation is made of
+large physically contiguous blocks and normally lies inside one class.
+
+`place_pair` makes ONE allocation with head-room, maps its classes with the library's store probe (pxl_mem_probe_pair: one
+0.3 ms probe per 2 GiB against a reference window of each class found so far) and returns a destination that straddles a class
+boundary (half of the XCD fronts on either side) and a source elsewhere.  This is topology discovery -- like asking which NUMA
+node a page lives on -- not a search over timings of the caller's kernel: nothing about the workload is measured, and the rule
+"destination across a boundary, boundary in the middle" is fixed.  The head-room stays allocated as long as the maps live
+(hipMalloc cannot give part of an allocation back), so this is for hosts with memory to spare: a 45 GB pair is placed inside a
+150 GiB allocation.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+GiB = 1 << 30
+
+
+def _probe(base_ptr, off_a, off_b, window, stream, reps=3):
+    us = C.c_float()
+    _lib.check(_lib.load().pxl_mem_probe_pair(C.c_void_p(base_ptr + off_a), C.c_void_p(base_ptr + off_b), window, reps, C.byref(us), stream))
+    return float(us.value)
+
+
+def map_classes(arena: torch.Tensor, step_gib=2, window_gib=1):
+    """Label 1 GiB windows of `arena` (a uint8 / float64 device tensor; OVERWRITTEN with zeros where probed) every `step_gib`:
+    returns (offsets in bytes, labels, info).  Two windows get the same label when the eight-front store probe between them runs
+    at the slow one of its two rates."""
+    assert arena.is_cuda and arena.is_contiguous()
+    nbytes = arena.numel() * arena.element_size()
+    base = arena.data_ptr()
+    window, step = int(window_gib * GiB), int(step_gib * GiB)
+    offs = list(range(0, nbytes - window + 1, step))
+    with torch.cuda.device(arena.device):
+        stream = C.c_void_p(torch.cuda.current_stream(arena.device).cuda_stream)
+        if len(offs) < 2:
+            return offs, [0] * len(offs), {"classes": 1, "probes": 0}
+        # calibration: every window against window 0 -- the times are bimodal (same class: slow, different: fast)
+        t0 = [None] + [_probe(base, o, offs[0], window, stream) for o in offs[1:]]
+        lo, hi = min(t0[1:]), max(t0[1:])
+        nprobes = len(offs) - 1
+        if hi >= 1.10 * lo:
+            thr = (lo * hi) ** 0.5
+        else:
+            # one rate only (everything of window 0's class, or nothing else): fall back to the part's two absolute rates,
+            # 5.6-5.9 TB/s within a class and 6.6-7.0 TB/s across classes -- the dividing line is 6.25 TB/s
+            thr = 2.0 * window / 6.25e6
+        labels = [0] + [-1] * (len(offs) - 1)
+        refs = [0]
+        for k in range(1, len(offs)):
+            if t0[k] > thr:
+                labels[k] = 0
+        for k in range(1, len(offs)):
+            if labels[k] >= 0:
+                continue
+            for c in range(1, len(refs)):
+                t = _probe(base, offs[k], offs[refs[c]], window, stream)
+                nprobes += 1
+                if t > thr:
+                    labels[k] = c
+                    break
+            if labels[k] < 0:
+                labels[k] = len(refs)
+                refs.append(k)
+    return offs, labels, {"classes": len(refs), "probes": nprobes, "probe_us_same_class": round(hi, 1), "probe_us_different_classes": round(lo, 1)}
+
+
+def place_pair(src_shape, dst_shape, dtype=torch.float64, device="cuda", headroom_gib=96, step_gib=2):
+    """(src, dst, info): a zero-filled source and a destination inside one allocation of (pair size + headroom_gib), the
+    destination centred on a boundary between two memory classes whenever the allocation contains one with enough room on both
+    sides, the source in a class the destination does not touch if there is one.  Keep `info["arena"]` alive as long as the maps
+    are in use (the tensors are views of it)."""
+    import math
+    dev = torch.device(device)
+    esz = torch.empty((), dtype=dtype).element_size()
+    ns, nd = math.prod(src_shape), math.prod(dst_shape)
+    al = (2 << 20)
+    bs, bd = -(-ns * esz // al) * al, -(-nd * esz // al) * al
+    free, _total = torch.cuda.mem_get_info(dev)
+    want = bs + bd + int(headroom_gib * GiB)
+    total = min(want, max(bs + bd + al, free - 6 * GiB))
+    total = total // al * al
+    arena = torch.empty(total, dtype=torch.uint8, device=dev)
+    offs, labels, cinfo = map_classes(arena, step_gib=step_gib)
+    step = int(step_gib * GiB)
+    # runs of equal label; a boundary sits between the last window of one run and the first of the next: take it half-way
+    bounds = []
+    for k in range(1, len(offs)):
+        if labels[k] != labels[k - 1]:
+            bounds.append((offs[k - 1] + offs[k] + GiB) // 2)
+    edges = [0] + bounds + [total]
+    best = None
+    for i, b in enumerate(bounds):
+        left, right = b - edges[i], edges[i + 2] - b          # room of the two classes either side of this boundary
+        half = bd // 2
+        score = min(left, right, half)
+        if best is None or score > best[0]:
+            best = (score, b, left, right)
+    how = "no class boundary inside the allocation: destination above the source (one class)"
+    dst_off = (total - bd) // al * al
+    src_off = 0
+    if best is not None and best[0] >= min(bd // 8, 1 * GiB):
+        score, b, left, right = best
+        # centre on the boundary, shifted as far as needed to stay inside the allocation
+        dst_off = b - bd // 2
+        dst_off = max(0, min(dst_off, total - bd)) // al * al
+        split = (b - dst_off) / bd
+        how = "destination across a class boundary (%.0f %% / %.0f %% of it on either side)" % (100 * split, 100 * (1 - split))
+        # source: the free stretch (before or after the destination) that fits, preferring labels the destination does not touch
+        dst_labels = {labels[k] for k in range(len(offs)) if offs[k] + GiB > dst_off and offs[k] < dst_off + bd}
+        cands = []
+        if dst_off >= bs:
+            cands += [o for o in range(0, dst_off - bs + 1, step)] + [dst_off - bs]
+        if total - (dst_off + bd) >= bs:
+            start = -(-(dst_off + bd) // al) * al
+            cands += [o for o in range(start, total - bs + 1, step)] + [total - bs]
+        if not cands:
+            raise RuntimeError("place_pair: head-room too small to hold the source beside the destination")
+
+        def foreign(o):          # share of the source's windows whose class the destination does not touch
+            ks = [k for k in range(len(offs)) if offs[k] + GiB > o and offs[k] < o + bs]
+            return sum(1 for k in ks if labels[k] not in dst_labels) / max(1, len(ks))
+        src_off = max(cands, key=lambda o: (round(foreign(o), 2), abs(o - dst_off)))
+        src_off = src_off // al * al
+    else:
+        src_off = 0
+    assert src_off + bs <= dst_off or dst_off + bd <= src_off
+    view = arena.view(dtype)
+    src = view[src_off // esz: src_off // esz + ns].view(tuple(src_shape))
+    dst = view[dst_off // esz: dst_off // esz + nd].view(tuple(dst_shape))
+    src.zero_()
+    runs = []
+    for k in range(len(offs)):
+        if not runs or runs[-1][0] != labels[k]:
+            runs.append([labels[k], offs[k] // GiB, offs[k] // GiB])
+        runs[-1][2] = offs[k] // GiB + 1
+    info = {"arena": arena, "allocation_GiB": round(total / GiB, 1), "src_offset_GiB": round(src_off / GiB, 2),
+            "dst_offset_GiB": round(dst_off / GiB, 2), "placement": how, "class_runs_label_from_to_GiB": runs}
+    info.update(cinfo)
+    return src, dst, info

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--placements", type=int, default=1, help="re-allocate the maps this many times (physical placement moves the kernel by up to 10 %%) and print every variant per placement")
+    ap.add_argument("--place", action="store_true", help="maps from pj.place_pair (destination across a boundary between two memory classes) instead of torch.empty")
     ap.add_argument("--strip", default=None, help="R/W: time the declination strip of rank R of W (interior rows only)")
     ap.add_argument("variants", nargs="+")
     args = ap.parse_args()
@@ -49,6 +50,13 @@ def main():
     if args.dtype == "f32":
         src = torch.randn((nc, ny_s, nx), dtype=torch.float32, device=dev)
         dst = torch.empty((nc, nyo_s, nxo), dtype=torch.float32, device=dev)
+    elif args.place:
+        import time
+        t0 = time.perf_counter()
+        src, dst, info = pj.place_pair((nc, ny_s, nx), (nc, nyo_s, nxo), dtype=torch.float64, device=dev)
+        arena_keep = info.pop("arena")
+        print("place_pair: %.2f s" % (time.perf_counter() - t0), info)
+        pj.fill_random_(src, 1234)
     else:
         src = torch.empty((nc, ny_s, nx), dtype=torch.float64, device=dev)
         dst = torch.empty((nc, nyo_s, nxo), dtype=torch.float64, device=dev)
