@@ -26,6 +26,30 @@ __global__ __launch_bounds__(256) void k_store(char* const* base, size_t bytes, 
         for (size_t i = q * piece + threadIdx.x; i < (q + 1) * piece && i < n; i += 256) p[i] = val;
 }
 
+// F fronts in one destination: front f = (XCD v, sub-front s) for F >= 8 (each XCD deals its blocks round-robin over its F / 8 pieces);
+// for F < 8 the XCDs v, v + F, ... share front v % F (their blocks interleave inside the piece)
+__global__ __launch_bounds__(256) void k_fronts(char* base, size_t total_bytes, int F) {
+    const int v = blockIdx.x & 7;
+    const size_t j = blockIdx.x >> 3, nj = gridDim.x >> 3;
+    const size_t piece_bytes = total_bytes / F;
+    const uint4 val = make_uint4(1, 2, 3, 4);
+    const size_t chunk = 4096;                          // uint4 per 64 KiB step
+    const size_t n = piece_bytes / 16;
+    if (F >= 8) {
+        const int per = F / 8;
+        const int s_ = (int)(j % per);
+        uint4* p = reinterpret_cast<uint4*>(base + (size_t)(v * per + s_) * piece_bytes);
+        for (size_t q = j / per; q * chunk < n; q += nj / per)
+            for (size_t i = q * chunk + threadIdx.x; i < (q + 1) * chunk && i < n; i += 256) p[i] = val;
+    } else {
+        const int share = 8 / F;                        // XCDs per front
+        uint4* p = reinterpret_cast<uint4*>(base + (size_t)(v % F) * piece_bytes);
+        const size_t jj = j * share + v / F, njj = nj * share;
+        for (size_t q = jj; q * chunk < n; q += njj)
+            for (size_t i = q * chunk + threadIdx.x; i < (q + 1) * chunk && i < n; i += 256) p[i] = val;
+    }
+}
+
 static hipStream_t st;
 static float run(char* const* dbase, size_t bytes, int only, int reps = 5) {
     std::vector<float> t(reps);
@@ -58,6 +82,27 @@ int main(int argc, char** argv) {
         for (int v = 0; v < 8; ++v) h[v] = arena + off[v];
         CHECK_HIP(hipMemcpy(dbase, h, sizeof h, hipMemcpyHostToDevice));
     };
+    if (argc > 3 && !strcmp(argv[3], "fronts")) {
+        // how many write fronts should a kernel keep inside ONE class?  8 GiB at the start of the allocation (one block, one class)
+        const size_t D = 8 * GiB;
+        for (int rep = 0; rep < 2; ++rep)
+            for (int F : {1, 2, 4, 8, 16, 32, 64, 128, 512}) {
+                std::vector<float> t(5);
+                hipEvent_t e0, e1;
+                CHECK_HIP(hipEventCreate(&e0)); CHECK_HIP(hipEventCreate(&e1));
+                for (int r = -1; r < 5; ++r) {
+                    CHECK_HIP(hipEventRecord(e0, st));
+                    hipLaunchKernelGGL(k_fronts, dim3(8 * 256 * 4), dim3(256), 0, st, arena, D, F);
+                    CHECK_HIP(hipEventRecord(e1, st));
+                    CHECK_HIP(hipEventSynchronize(e1));
+                    if (r >= 0) CHECK_HIP(hipEventElapsedTime(&t[r], e0, e1));
+                }
+                std::sort(t.begin(), t.end());
+                printf("{\"fronts\": %d, \"GBs\": %.0f}\n", F, D / 1e6 / t[2]);
+                fflush(stdout);
+            }
+        return 0;
+    }
     if (argc > 3 && !strcmp(argv[3], "classes")) {
         // which parts of the allocation behave like "different regions"?  Windows of 1 GiB every `stride` GiB; for every pair
         // (a, b): XCDs 0, 2, 4, 6 write four 256 MiB pieces of window a, XCDs 1, 3, 5, 7 of window b (a == b: all eight
