@@ -229,7 +229,7 @@ def main():
                     help="allocate the source and the destination separately (round 1's and early round 2's default)")
     ap.add_argument("--placed", dest="arena", action="store_const", const="placed",
                     help="class-aware placement (pj.place_pair): the destination across a boundary between two of the HBM's three "
-                         "memory classes, found with the library's store probe (DESIGN 9 item 6).  N = 1 only.  The default run reports "
+                         "memory classes, found with the library's store probe (DESIGN 9 item 6); with N > 1 every rank places its own strip pair.  The default run reports "
                          "it beside the plain first placement for cfg4 / cfg3 / cfg3s (configs block) without making it the headline")
     ap.add_argument("--keep-placement", default="first", choices=["first", "best"],
                     help="which probed placement the timed steps run on (first = unselected headline)")
@@ -347,8 +347,6 @@ def bench_reproject(args, rank, world, dev):
     nx, ny, nc = shape_in
     nxo, nyo = shape_out
     sh = pj.DecStripReprojector(shape_in, wcs_in, shape_out, wcs_out, rank, world, dev)
-    if args.arena == "placed" and world > 1:
-        sys.exit("bench.py --placed is a one-GPU option")
     src, dst, placement = place_buffers(sh, 1 if args.arena == "placed" else args.placements, dev, args.keep_placement, arena=args.arena)
     torch.cuda.synchronize(dev)
     # ---- choose the halo transport (N > 1).  Candidates in order: "native" = the library's own sharded step (RCCL

@@ -40,7 +40,7 @@ struct ReprojParams {
     int32_t ntx, nty;      // tiles along RA / DEC
     int64_t ntiles, tiles_per_xcd;
     int64_t xchunk;        // tiles an XCD takes in one piece (xcd_tile below); tiles_per_xcd = one contiguous eighth each
-    int32_t flags;         // tuning/diagnostics: 1 = skip source loads, 2 = skip stores, 4 = no XCD remap, 8 / 16 = tile order 1 / 2 of xcd_tile, 64 = stores only, 128 = round-2 row loop (four LDS taps per output value), 256 = round-2 waits (DMAs counted, stores ignored)
+    int32_t flags;         // tuning/diagnostics: 1 = skip source loads, 2 = skip stores, 4 = no XCD remap, 8 / 16 = tile order 1 / 2 of xcd_tile, 64 = stores only
     // LDS-DMA kernel only
     int32_t ns, pf;        // ring slots (power of two), prefetch distance in output rows
     const double* zero_page;   // 16 bytes of zeros in device memory

@@ -31,23 +31,6 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// wait until the DMA of the row that is `k` rows older than the newest requested row has landed
-template <int NCH>
-__device__ __forceinline__ void wait_rows(int k) {
-    // k = rows requested after the one needed.  Rounding k down is always safe (a stricter wait), so clamp to
-    // 7: eight cases compile to a three-level branch tree instead of sixteen.
-    switch (k > 7 ? 7 : k) {
-        case 0: wait_vm<0>(); break;
-        case 1: wait_vm<1 * NCH>(); break;
-        case 2: wait_vm<2 * NCH>(); break;
-        case 3: wait_vm<3 * NCH>(); break;
-        case 4: wait_vm<4 * NCH>(); break;
-        case 5: wait_vm<5 * NCH>(); break;
-        case 6: wait_vm<6 * NCH>(); break;
-        default: wait_vm<7 * NCH>(); break;
-    }
-}
-
 // wait until at most k vector-memory instructions of this wave are outstanding (k rounded DOWN to an immediate the
 // switch carries: a stricter wait is always safe).  vmcnt is a 6-bit counter on gfx9 and retires in issue order,
 // loads and stores alike.
@@ -260,51 +243,6 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
         }
         return;
     }
-    if (p.flags & 128) {
-        // diagnostics (A/B within one process): the round-2 row loop -- four LDS taps per output value in every output
-        // row, waits that count DMAs only
-        for (int rr = 0; rr < nrows; ++rr) {
-            const int t0 = __builtin_amdgcn_readlane(my_t0, rr);
-            const double fy = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_fy), rr),
-                                               __builtin_amdgcn_readlane(__double2loint(my_fy), rr));
-            {
-                const int ra = (rr + p.pf < nrows) ? rr + p.pf : nrows - 1;
-                int tmax = __builtin_amdgcn_readlane(my_t0, ra) + 1;
-                const int tlim = t0 + p.ns - 1;
-                if (tmax > tlim) tmax = tlim;
-                while (treq < tmax) issue_next();
-            }
-            wait_rows<NCH>(treq - (t0 + 1));
-            const int st = (p.dypos ? t0 : t0 + 1) & ns_mask;
-            const int sb = (p.dypos ? t0 + 1 : t0) & ns_mask;
-            const T* Tp = lds + st * p.seg;
-            const T* Bp = lds + sb * p.seg;
-            const double wy = 1 - fy;
-#pragma unroll
-            for (int q = 0; q < PAIRS; ++q) {
-                alignas(16) T v[EPL];
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) {
-                    const int d = dloc[q][e];
-                    const double wx = 1 - fx[q][e];
-                    const double top = wx * (double)Tp[d] + fx[q][e] * (double)Tp[d + 1];
-                    const double bot = wx * (double)Bp[d] + fx[q][e] * (double)Bp[d + 1];
-                    v[e] = (T)(wy * top + fy * bot);
-                }
-                T* o = orow + q * CW;
-                if (p.flags & 2) { if (v[0] == (T)1.2345e30) o[0] = v[1]; }
-                else if (vec_store) { if (act[q][0]) *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(v); }
-                else {
-#pragma unroll
-                    for (int e = 0; e < EPL; ++e) if (act[q][e]) o[e] = v[e];
-                }
-            }
-            orow += p.nxo;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        return;
-    }
-
     // ---- the row loop.  The horizontal interpolant of a source row at this lane's columns,
     //          h(t) = (1 - fx) * row_t[d] + fx * row_t[d + 1],
     // is the `top` of every output row whose upper source row is t and the `bot` of every output row whose lower one
@@ -327,8 +265,7 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
                 h[q][e] = wx[q][e] * (double)R[d] + fx[q][e] * (double)R[d + 1];
             }
     };
-    const bool count_stores = vec_store && (c0 + TW <= p.nxo) && !(p.flags & (2 | 256));
-    const bool exact_wait = !(p.flags & 256);
+    const bool count_stores = vec_store && (c0 + TW <= p.nxo) && !(p.flags & 2);
     int th = INT32_MIN / 2;                                     // no row interpolated yet
     for (int rr = 0; rr < nrows; ++rr) {
         const int t0 = __builtin_amdgcn_readlane(my_t0, rr);
@@ -342,8 +279,7 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
         }
         if (t0 != th) {
             // rows t0 and t0 + 1 are needed; t0 + 1 was requested last of the two
-            if (exact_wait) wait_vm_upto(vm_total - __builtin_amdgcn_readlane(marks, (t0 + 1) & ns_mask));
-            else wait_rows<NCH>(treq - (t0 + 1));
+            wait_vm_upto(vm_total - __builtin_amdgcn_readlane(marks, (t0 + 1) & ns_mask));
             if (t0 == th + 1) {
 #pragma unroll
                 for (int q = 0; q < PAIRS; ++q)

@@ -35,13 +35,16 @@ def test_bench_self_launch_two_ranks():
     assert "gloo" in d["config"]["parallelism"]
 
 
-@pytest.mark.parametrize("workload", ["cfg2", "cfg5", "cfg5:pairs"])
+@pytest.mark.parametrize("workload", ["cfg2", "cfg2:placed", "cfg5", "cfg5:pairs"])
 def test_bench_contract(workload):
     env = dict(os.environ, PXL_BENCH_POINTS="2e6")
+    extra = []
     if workload.endswith(":pairs"):          # the sampler the default 1e9-point run takes (row-pair copy rebuilt inside every step)
         workload, env["PXL_BENCH_SAMPLER"] = "cfg5", "pairs"
+    if workload.endswith(":placed"):         # class-aware placement of the maps (pj.place_pair), as the default run's configs block uses it
+        workload, extra = "cfg2", ["--placed", "--no-cpu-baseline"]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "3",
-                        "--warmup", "1", "--check"], capture_output=True, text=True, timeout=600, env=env)
+                        "--warmup", "1", "--check"] + extra, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
@@ -61,8 +64,12 @@ def test_bench_contract(workload):
         assert d["check"]["bit_identical"] and d["check"]["points_checked"] > 0
     if workload == "cfg2":
         assert d["check"]["bit_identical"] and d["check"]["max_abs_err"] == 0.0
-        cb = d["cpu_baseline"]
-        assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+        if extra:
+            al = d["config"]["buffer_placement"]["allocation"]
+            assert al["classes"] >= 1 and "destination" in al["placement"] and al["class_runs_label_from_to_GiB"]
+        else:
+            cb = d["cpu_baseline"]
+            assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
 
 
 def test_native_cpp_host(tmp_path):
