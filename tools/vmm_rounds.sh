@@ -1,8 +1,8 @@
 #!/bin/bash
-# plain torch allocations against pj.place_pair, alternating fresh processes, cfg3 and cfg4 (full launch, stores only)
-for k in 1 2 3; do
-  for wl in cfg3 cfg4; do
-    python tools/tune_reproject.py --workload $wl --rounds 5 "" "flags=64" 2>&1 | grep -v amdgpu.ids | grep -v "^workload" | sed "s/^/plain  $wl: /"
-    python tools/tune_reproject.py --workload $wl --rounds 5 --place "" "flags=64" 2>&1 | grep -v amdgpu.ids | grep -v "^workload" | sed "s/^/placed $wl: /"
-  done
+R=$(pwd)
+cd /tmp && export TMPDIR=/tmp
+for mode in 0 1; do
+  rm -rf $R/gpurun_out/uw_$mode; mkdir -p $R/gpurun_out/uw_$mode
+  PXL_UNWIND_MSPACE=$mode rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/uw_$mode -- python3 $R/tools/prof_unwind.py > /dev/null 2>&1
+  echo "PXL_UNWIND_MSPACE=$mode"; grep -h "k_unwind\|k_scan_wsums" $R/gpurun_out/uw_$mode/*/*kernel_stats.csv | cut -c1-160
 done
