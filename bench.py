@@ -22,6 +22,11 @@ Workloads (BASELINE.json configs; natural Clenshaw-Curtis shapes, ny = nx/2 + 1)
     cfg2: (4096, 2049) -> (8192, 4097) (Infinity-Cache resident; informational).
     cfg5: 1e9 scattered (ra, dec) points sampled from a (43200, 21601) map replicated per GPU.
 
+Where the maps live: by default they are placed by pj.place_pair (one allocation with head-room, the HBM's three memory classes
+mapped with the library's store probe, the destination across a class boundary -- DESIGN.md 9 item 6; a fixed rule, no timing of
+this workload, no candidates); --arena / --two-allocations give plain allocations, and the default run reports the plain first
+placement of every reprojection config beside the class-aware one.
+
 The default run (N = 1, workload cfg4) appends, after the headline and outside its timed region, a "configs" block
 with the other BASELINE configs measured in the same process (cfg2, cfg3, cfg3s, cfg5 at 1e9 points: ms per step,
 kernel average, roofline fraction, oracle check), an "evaluators" block (posmap, pix2sky!, sky2pix! on the GPU) and
@@ -141,8 +146,9 @@ def cpu_baseline_reproject(shape_in, wcs_in, shape_out, wcs_out, budget_s=12.0):
 def place_buffers(sh, candidates, dev, keep="first", arena=False):
     """Allocate and fill the resident maps.  Where the driver puts a 20 GB buffer physically moves this
     HBM-bound kernel by up to 10 % (profiles/README.md: same virtual addresses, re-allocated, 7.35-8.13 ms).
-    The headline number comes from the FIRST allocation, made by the fixed policy of DecStripReprojector.alloc_pair (one
-    allocation, destination above the source; --two-allocations for two separate ones).  With
+    The headline number comes from the FIRST allocation, made by one fixed policy: pj.place_pair (class-aware: destination
+    across a boundary between two memory classes, found by a topology probe), or with --arena DecStripReprojector.alloc_pair (one
+    plain allocation, destination above the source), or --two-allocations.  With
     --placements N > 1 the other N - 1 allocations are only probed (4 launches each, outside every timed step) so
     that the line can say where the first one sits in the spread (roofline.frac_first/median/best_placement);
     --keep-placement best restores round 1's behaviour of running the timed steps on the fastest candidate."""
@@ -207,6 +213,46 @@ def load_traffic(workload):
     return None
 
 
+def measure_traffic(workload, timeout_s=150):
+    """HBM bytes per launch of k_reproject_dma measured NOW: two child runs of this script under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, the program directly after `--`, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes; KiB -> bytes; FETCH_SIZE doubled on gfx950).  The caller has released its
+    device memory; the children are ordinary child processes (nothing is exec'ed over this one).  Returns (bytes, detail) or
+    (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="pxl_pmc_")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--workload", workload, "--steps", "3", "--warmup", "1", "--sustain-seconds", "0", "--no-cpu-baseline", "--no-configs",
+                   "--no-traffic"]
+            env = dict(os.environ, TMPDIR=tmp)
+            try:
+                r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 --pmc %s did not finish within %d s" % (counter, timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, (r.stderr or "").strip().splitlines()[-1:] or "")
+            vals = sorted(float(row["Counter_Value"]) for row in csv.DictReader(open(files[0])) if "k_reproject_dma" in row["Kernel_Name"])
+            if not vals:
+                return None, "no k_reproject_dma rows in the %s pass" % counter
+            out[counter] = (vals[len(vals) // 2], len(vals))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch = 2.0 * out["FETCH_SIZE"][0] * 1024.0
+    write = out["WRITE_SIZE"][0] * 1024.0
+    return fetch + write, {"fetch_bytes_x2": fetch, "write_bytes": write, "launches_sampled": [out["FETCH_SIZE"][1], out["WRITE_SIZE"][1]]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,17 +266,21 @@ def main():
     ap.add_argument("--placements", type=int, default=int(os.environ.get("PXL_BENCH_PLACEMENTS", "1")),
                     help="buffer placements probed at setup (default 1: just the first allocation, which is what the "
                          "headline always reports unless --keep-placement best)")
-    ap.add_argument("--arena", dest="arena", action="store_true", default=os.environ.get("PXL_BENCH_ARENA", "1") != "0",
-                    help="(default) carve the source and destination maps out of ONE allocation, destination above the source: "
-                         "DecStripReprojector.alloc_pair, a fixed policy any caller can use, nothing probed.  Where the destination "
-                         "lands physically moves the kernel by up to 10 %% (DESIGN 9 item 6): this arrangement gave the fast case in "
-                         "20 of 24 processes on 9 boxes, two separate allocations in about half")
+    ap.add_argument("--placed", dest="arena", action="store_const", const="placed",
+                    default={"1": True, "0": False}.get(os.environ.get("PXL_BENCH_ARENA", "placed"), "placed"),
+                    help="(default) class-aware placement of the maps, pj.place_pair: ONE allocation with 144 GiB of head-room, its three "
+                         "memory classes mapped with the library's store probe (pxl_mem_probe_pair, ~100 probes of 0.3 ms), the destination "
+                         "put across a class boundary, the source in a class it does not touch.  The reprojection's eight XCD write fronts "
+                         "store at 6.8-7.1 TB/s split over two classes and at 5.8-6.0 TB/s inside one, which is where a plain allocation "
+                         "normally lies (DESIGN 9 item 6).  Topology discovery by a fixed rule: nothing about this workload is timed, no "
+                         "candidates are compared.  With N > 1 every rank places its own strip pair.  The default run also reports the "
+                         "plain first placement of the same workload (configs.*.plain_first_placement)")
+    ap.add_argument("--arena", dest="arena", action="store_true",
+                    help="plain allocation, nothing probed: source and destination carved out of ONE allocation, destination above the "
+                         "source (DecStripReprojector.alloc_pair; the default until round 3: fast for the 45 GB pair in 20 of 24 processes "
+                         "because the driver's block boundary at 32 GiB falls into the destination, slow otherwise)")
     ap.add_argument("--two-allocations", dest="arena", action="store_false",
                     help="allocate the source and the destination separately (round 1's and early round 2's default)")
-    ap.add_argument("--placed", dest="arena", action="store_const", const="placed",
-                    help="class-aware placement (pj.place_pair): the destination across a boundary between two of the HBM's three "
-                         "memory classes, found with the library's store probe (DESIGN 9 item 6); with N > 1 every rank places its own strip pair.  The default run reports "
-                         "it beside the plain first placement for cfg4 / cfg3 / cfg3s (configs block) without making it the headline")
     ap.add_argument("--keep-placement", default="first", choices=["first", "best"],
                     help="which probed placement the timed steps run on (first = unselected headline)")
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the output of the timed run is always "
@@ -242,6 +292,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path); gloo = host-staged halo, only for rehearsing "
                          "the N-rank flow on a box with fewer GPUs than ranks (with PXL_BENCH_SHARE_GPU=1)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not measure roofline.traffic with two rocprofv3 --pmc child passes after the headline (N = 1, default "
+                         "workload); the committed profile of the same workload is quoted instead")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the side measurements the default run appends after the headline (configs / evaluators blocks "
                          "and the evaluators' CPU baselines)")
@@ -281,6 +334,19 @@ def main():
         result = bench_scattered(args, rank, world, dev)
     else:
         result = bench_reproject(args, rank, world, dev)
+    if world == 1 and args.workload == "cfg4" and not args.no_traffic and "roofline" in result:
+        # roofline.traffic measured in THIS run (the maps of the headline are gone by now; nothing else is on the device)
+        torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        tb, detail = measure_traffic(args.workload)
+        if tb is not None:
+            result["roofline"]["traffic"] = tb
+            result["roofline"]["traffic_source"] = ("measured in this run: two child passes of this script under rocprofv3 --kernel-trace --pmc "
+                                                    "FETCH_SIZE / --pmc WRITE_SIZE (separate passes; KiB -> bytes; FETCH_SIZE x2 on gfx950), median "
+                                                    "over the k_reproject_dma launches; %.0f s" % (time.perf_counter() - t0))
+            result["roofline"]["traffic_detail"] = detail
+        else:
+            result["roofline"]["traffic_source"] = (result["roofline"].get("traffic_source") or "") + "; live measurement failed: %s" % detail
     if world == 1 and args.workload == "cfg4" and not args.no_configs:
         side_measurements(args, dev, result)
     if rank == 0:
@@ -678,26 +744,31 @@ def scattered_check(m, wcs, shape, sky, out, world, dev, npick=4096):
 def side_measurements(args, dev, result):
     """After the headline, outside its timed region (N = 1, default workload): the other BASELINE configs, the
     evaluators the reference has, and the CPU oracle's rates for them -- so that one driver-observed line carries
-    what used to live only in builder-kept files under profiles/."""
+    what used to live only in builder-kept files under profiles/.  Every reprojection config is measured twice: with the
+    class-aware placement the headline uses (pj.place_pair) and with a plain, unprobed first placement (alloc_pair)."""
     cfgs = {}
-    for name in ("cfg2", "cfg3", "cfg3s"):
+    for name in ("cfg2", "cfg3", "cfg3s", "cfg4"):
         a = argparse.Namespace(**vars(args))
         a.workload, a.steps, a.warmup, a.sustain_seconds, a.no_cpu_baseline, a.placements = name, 10, 2, 0.0, True, 1
-        torch.cuda.empty_cache()
-        r = bench_reproject(a, 0, 1, dev)
-        cfgs[name] = {"workload": r["config"]["workload"], "Mpix_s": r["value"], "ms_per_step": r["ms_per_step"],
-                      "kernel_ms_avg": r["roofline"]["kernel_ms_avg"], "frac": r["roofline"]["frac"],
-                      "achieved_GBs": r["roofline"]["achieved"], "bytes_per_output_value": r["config"]["bytes_per_output_value"],
-                      "traffic": r["roofline"]["traffic"], "steps": a.steps, "check": r["check"]}
         if name == "cfg2":
-            cfgs[name]["note"] = "268 MB of output: Infinity-Cache resident, not roofline evidence (SURVEY 8(d))"
+            a.arena = True
+            r = variant(a, dev)
+            r["note"] = "268 MB of output: Infinity-Cache resident, not roofline evidence (SURVEY 8(d)); plain allocation"
+            cfgs[name] = r
+            continue
+        if name == "cfg4" and args.arena == "placed":       # the headline IS the class-aware run of this config
+            placed = {"Mpix_s": result["value"], "ms_per_step": result["ms_per_step"], "kernel_ms_avg": result["roofline"]["kernel_ms_avg"],
+                      "frac": result["roofline"]["frac"], "check": result["check"], "note": "the headline above"}
         else:
-            cfgs[name]["class_aware_placement"] = placed_variant(a, dev)
-    a = argparse.Namespace(**vars(args))
-    a.workload, a.steps, a.warmup, a.sustain_seconds, a.no_cpu_baseline, a.placements = "cfg4", 10, 2, 0.0, True, 1
-    cfgs["cfg4"] = {"workload": result["config"]["workload"], "ms_per_step": result["ms_per_step"], "kernel_ms_avg": result["roofline"]["kernel_ms_avg"],
-                    "frac": result["roofline"]["frac"], "note": "the headline above (plain first placement)",
-                    "class_aware_placement": placed_variant(a, dev)}
+            a.arena = "placed"
+            placed = variant(a, dev)
+        a.arena = True
+        plain = variant(a, dev)
+        cfgs[name] = {"workload": plain.pop("workload"), "bytes_per_output_value": plain.pop("bytes_per_output_value"),
+                      "ms_per_step": placed["ms_per_step"], "kernel_ms_avg": placed["kernel_ms_avg"], "frac": placed["frac"],
+                      "check": placed["check"], "class_aware_placement": placed, "plain_first_placement": plain}
+        cfgs[name]["class_aware_placement"].pop("workload", None)
+        cfgs[name]["class_aware_placement"].pop("bytes_per_output_value", None)
     a = argparse.Namespace(**vars(args))
     a.workload, a.steps, a.warmup = "cfg5", 6, 2
     torch.cuda.empty_cache()
@@ -713,20 +784,22 @@ def side_measurements(args, dev, result):
         result["cpu_baseline"].update(cpu_baseline_evaluators())
 
 
-def placed_variant(a, dev):
-    """The same workload with its maps placed by pj.place_pair (destination across a boundary between two memory classes)."""
-    a = argparse.Namespace(**vars(a))
-    a.arena = "placed"
+def variant(a, dev):
+    """One reprojection workload with the allocation policy of a.arena, as a compact record."""
     torch.cuda.empty_cache()
     r = bench_reproject(a, 0, 1, dev)
     torch.cuda.empty_cache()
+    out = {"workload": r["config"]["workload"], "bytes_per_output_value": r["config"]["bytes_per_output_value"], "Mpix_s": r["value"],
+           "ms_per_step": r["ms_per_step"], "kernel_ms_avg": r["roofline"]["kernel_ms_avg"], "frac": r["roofline"]["frac"],
+           "steps": a.steps, "check": r["check"]}
     al = r["config"]["buffer_placement"]["allocation"]
-    return {"Mpix_s": r["value"], "ms_per_step": r["ms_per_step"], "kernel_ms_avg": r["roofline"]["kernel_ms_avg"], "frac": r["roofline"]["frac"],
-            "check": r["check"], "placement": al["placement"], "allocation_GiB": al["allocation_GiB"], "classes": al["classes"],
-            "class_runs_label_from_to_GiB": al["class_runs_label_from_to_GiB"], "probe_us_same_class": al["probe_us_same_class"],
-            "probe_us_different_classes": al["probe_us_different_classes"],
-            "note": "pj.place_pair: topology discovery with the library's store probe, nothing about this workload is timed or selected; "
-                    "not the headline"}
+    if isinstance(al, dict):
+        out.update({"placement": al["placement"], "allocation_GiB": al["allocation_GiB"], "classes": al["classes"],
+                    "class_runs_label_from_to_GiB": al["class_runs_label_from_to_GiB"], "probe_us_same_class": al["probe_us_same_class"],
+                    "probe_us_different_classes": al["probe_us_different_classes"]})
+    else:
+        out["allocation"] = al
+    return out
 
 
 def _median_ms(fn, dev, reps=7):

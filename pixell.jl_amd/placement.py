@@ -12,7 +12,9 @@ boundary (half of the XCD fronts on either side) and a source elsewhere.  This i
 node a page lives on -- not a search over timings of the caller's kernel: nothing about the workload is measured, and the rule
 "destination across a boundary, boundary in the middle" is fixed.  The head-room stays allocated as long as the maps live
 (hipMalloc cannot give part of an allocation back), so this is for hosts with memory to spare: a 45 GB pair is placed inside a
-150 GiB allocation.
+186 GiB allocation (144 GiB of head-room: a fresh device hands out one class for 64 GiB and the next for another 64, so the third
+class -- where the source should go: with the source in a class the destination also uses the launch loses 3-4 % -- only shows
+up beyond 128 GiB).
 """
 import ctypes as C
 
@@ -72,7 +74,7 @@ def map_classes(arena: torch.Tensor, step_gib=2, window_gib=1):
     return offs, labels, {"classes": len(refs), "probes": nprobes, "probe_us_same_class": round(hi, 1), "probe_us_different_classes": round(lo, 1)}
 
 
-def place_pair(src_shape, dst_shape, dtype=torch.float64, device="cuda", headroom_gib=96, step_gib=2):
+def place_pair(src_shape, dst_shape, dtype=torch.float64, device="cuda", headroom_gib=144, step_gib=2):
     """(src, dst, info): a zero-filled source and a destination inside one allocation of (pair size + headroom_gib), the
     destination centred on a boundary between two memory classes whenever the allocation contains one with enough room on both
     sides, the source in a class the destination does not touch if there is one.  Keep `info["arena"]` alive as long as the maps
