@@ -161,8 +161,16 @@ def place_buffers(sh, candidates, dev, keep="first", arena=False):
     for k in range(max(1, candidates)):
         if arena == "placed":   # one allocation with head-room, its memory classes mapped with the library's store probe, the
             # destination put across a class boundary (pixell.jl_amd/placement.py): topology discovery, no timing of this workload
-            src, dst, pinfo = pj.place_pair(sh.src_tensor_shape(), sh.dst_tensor_shape(), device=dev)
-            holds.append(pinfo.pop("arena"))
+            try:
+                src, dst, pinfo = pj.place_pair(sh.src_tensor_shape(), sh.dst_tensor_shape(), device=dev)
+                pinfo.pop("arena")                   # the views keep the allocation alive
+            except Exception as e:                   # noqa: BLE001 -- never lose a run to the placement: plain allocation, and say so
+                print("bench.py: pj.place_pair failed (%s: %s); plain allocation instead" % (type(e).__name__, str(e)[:200]), file=sys.stderr, flush=True)
+                torch.cuda.empty_cache()
+                src, dst, hold = sh.alloc_pair()
+                pinfo = {"placement": "place_pair FAILED (%s): plain allocation, destination above the source" % type(e).__name__,
+                         "allocation_GiB": None, "classes": None, "class_runs_label_from_to_GiB": None, "probe_us_same_class": None,
+                         "probe_us_different_classes": None, "src_offset_GiB": None, "dst_offset_GiB": None}
         elif arena:       # one allocation, destination above the source (sharding.alloc_pair: a fixed policy, nothing probed)
             src, dst, hold = sh.alloc_pair()
             holds.append(hold)
@@ -837,8 +845,17 @@ def gpu_evaluators(dev):
     def posmap():
         s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         pj._lib.check(lib.pxl_posmap_car_f64(C.byref(wref), sh2, 0, shape[1], C.c_void_p(ra.data_ptr()), C.c_void_p(dec.data_ptr()), 1, s))
-    rec("posmap", _median_ms(posmap, dev), 16.0 * npx, npx, "Mpix_s", "enmap_ops.jl:190-203 (safe=true), 43200x21601, write-only 16 B/pixel")
+    rec("posmap", _median_ms(posmap, dev), 16.0 * npx, npx, "Mpix_s", "enmap_ops.jl:190-203 (safe=true), 43200x21601, write-only 16 B/pixel; two plain allocations")
     del ra, dec
+    torch.cuda.empty_cache()
+    try:    # the same launch with its two output maps in different memory classes (pj.place_streams)
+        (ra, dec), sinfo = pj.place_streams([(shape[1], shape[0])] * 2, device=dev)
+        rec("posmap, RA and DEC maps in different memory classes", _median_ms(posmap, dev), 16.0 * npx, npx, "Mpix_s",
+            "the same launch; buffers from pj.place_streams: classes %s" % [b["class"] for b in sinfo["buffers"]])
+        del ra, dec, sinfo
+    except Exception as e:                                  # noqa: BLE001 -- a side measurement: reported, not fatal
+        out["posmap, RA and DEC maps in different memory classes"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    torch.cuda.empty_cache()
     n = 200_000_000
     pix = torch.empty((n, 2), dtype=torch.float64, device=dev)
     pj.fill_random_(pix, 1, kind="uniform")

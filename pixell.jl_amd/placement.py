@@ -147,3 +147,46 @@ def place_pair(src_shape, dst_shape, dtype=torch.float64, device="cuda", headroo
             "dst_offset_GiB": round(dst_off / GiB, 2), "placement": how, "class_runs_label_from_to_GiB": runs}
     info.update(cinfo)
     return src, dst, info
+
+
+def place_streams(shapes, dtype=torch.float64, device="cuda", headroom_gib=144, step_gib=2):
+    """(tensors, info): one buffer per shape inside ONE allocation, each in a memory class of its own as far as the allocation
+    has classes with room (buffer k goes into the longest free run of the class used least so far).  For kernels that write several
+    streams at once -- `posmap` writes its RA and its DEC map together: 6.8 TB/s with the two in different classes, 5.3 TB/s with
+    both in one (profiles/r03_class_streams.jsonl) -- or that should keep their reads away from their writes.  Keep info["arena"]
+    alive as long as the tensors are in use."""
+    import math
+    dev = torch.device(device)
+    esz = torch.empty((), dtype=dtype).element_size()
+    al = 2 << 20
+    sizes = [-(-math.prod(sh) * esz // al) * al for sh in shapes]
+    free, _total = torch.cuda.mem_get_info(dev)
+    total = min(sum(sizes) + int(headroom_gib * GiB), max(sum(sizes) + al, free - 6 * GiB)) // al * al
+    arena = torch.empty(total, dtype=torch.uint8, device=dev)
+    offs, labels, cinfo = map_classes(arena, step_gib=step_gib)
+    step = int(step_gib * GiB)
+    # free runs of one label: [label, start, end) in bytes (a window stands for the step after it)
+    runs = []
+    for k in range(len(offs)):
+        end = min(offs[k] + step, total)
+        if runs and runs[-1][0] == labels[k]:
+            runs[-1][2] = end
+        else:
+            runs.append([labels[k], offs[k], end])
+    used = {}
+    out, where = [], []
+    view = arena.view(dtype)
+    for sh, size in zip(shapes, sizes):
+        fits = [r for r in runs if r[2] - r[1] >= size]
+        if not fits:
+            raise RuntimeError("place_streams: no run of one memory class holds %d MiB; more head-room needed" % (size >> 20))
+        r = min(fits, key=lambda r: (used.get(r[0], 0), -(r[2] - r[1])))
+        o = -(-r[1] // al) * al
+        n = math.prod(sh)
+        out.append(view[o // esz: o // esz + n].view(tuple(sh)))
+        where.append({"class": r[0], "offset_GiB": round(o / GiB, 2)})
+        used[r[0]] = used.get(r[0], 0) + 1
+        r[1] = o + size
+    info = {"arena": arena, "allocation_GiB": round(total / GiB, 1), "buffers": where}
+    info.update(cinfo)
+    return out, info

@@ -60,3 +60,23 @@ def test_map_classes_and_place_pair(pj, O, dev):
     exp = O.reproject(wcs_in, shape_in, src[:, 100:104, :].cpu().numpy(), wcs_out, shape_out, src_row0=100, src_nrows=4, dst_row0=201, dst_nrows=4)
     assert np.array_equal(dst[:, 201:205, :].cpu().numpy().view(np.int64), exp.view(np.int64))
     plan.close()
+
+
+def test_place_streams(pj, dev):
+    """Buffers for kernels that write several streams at once (posmap's RA and DEC maps): disjoint views of one allocation, each in a
+    memory class of its own when the allocation has more than one, and posmap through them gives the bits of posmap on plain ones."""
+    shape, wcs = pj.fullsky_geometry(2 * math.pi / 4800)
+    (ra, dec), info = pj.place_streams([(shape[1], shape[0])] * 2, device=dev, headroom_gib=40)
+    assert tuple(ra.shape) == tuple(dec.shape) == (shape[1], shape[0]) and ra.dtype == torch.float64
+    lo_a, hi_a, lo_b, hi_b = ra.data_ptr(), ra.data_ptr() + ra.numel() * 8, dec.data_ptr(), dec.data_ptr() + dec.numel() * 8
+    assert hi_a <= lo_b or hi_b <= lo_a
+    assert len(info["buffers"]) == 2 and info["classes"] >= 1
+    if info["classes"] > 1:
+        assert info["buffers"][0]["class"] != info["buffers"][1]["class"]
+    import ctypes as C
+    lib = pj.load_library()
+    sh2 = (C.c_int64 * 2)(shape[0], shape[1])
+    pj._lib.check(lib.pxl_posmap_car_f64(C.byref(wcs.to_struct()), sh2, 0, shape[1], C.c_void_p(ra.data_ptr()), C.c_void_p(dec.data_ptr()), 1, None))
+    ra0, dec0 = pj.posmap(shape, wcs, device=dev)
+    torch.cuda.synchronize()
+    assert torch.equal(ra.view(torch.int64), ra0.data.view(torch.int64)) and torch.equal(dec.view(torch.int64), dec0.data.view(torch.int64))
