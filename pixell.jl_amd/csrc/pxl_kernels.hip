@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 #include "pxl_device.h"
 

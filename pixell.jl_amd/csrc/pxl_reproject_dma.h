@@ -265,7 +265,11 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
                 h[q][e] = wx[q][e] * (double)R[d] + fx[q][e] * (double)R[d + 1];
             }
     };
-    const bool count_stores = vec_store && (c0 + TW <= p.nxo) && !(p.flags & 2);
+    // FAST: a tile with every lane inside the map, 16-byte stores and no diagnostics flag -- the stores are unconditional (no
+    // exec masking, no flag tests: a third of the loop's scalar instructions), and each of them is certain to issue, so they are
+    // counted for the exact waits.  Edge tiles and the diagnostic launches take the general form.
+    auto row_loop = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
     int th = INT32_MIN / 2;                                     // no row interpolated yet
     for (int rr = 0; rr < nrows; ++rr) {
         const int t0 = __builtin_amdgcn_readlane(my_t0, rr);
@@ -307,16 +311,20 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
 #pragma unroll
             for (int e = 0; e < EPL; ++e) v[e] = (T)(wa * hA[q][e] + wb * hB[q][e]);
             T* o = orow + q * CW;
-            if (p.flags & 2) { if (v[0] == (T)1.2345e30) o[0] = v[1]; }       // diagnostics: keep v live, never store
+            if (FAST) *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(v);
+            else if (p.flags & 2) { if (v[0] == (T)1.2345e30) o[0] = v[1]; }       // diagnostics: keep v live, never store
             else if (vec_store) { if (act[q][0]) *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(v); }
             else {
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) if (act[q][e]) o[e] = v[e];
             }
         }
-        if (count_stores) vm_total += PAIRS;
+        if (FAST) vm_total += PAIRS;
         orow += p.nxo;
     }
+    };
+    if (vec_store && (c0 + TW <= p.nxo) && p.flags == 0) row_loop(std::true_type{});
+    else row_loop(std::false_type{});
 }
 
 template <typename T>
