@@ -221,7 +221,7 @@ def load_traffic(workload):
     return None
 
 
-def measure_traffic(workload, timeout_s=150):
+def measure_traffic(workload, timeout_s=90):
     """HBM bytes per launch of k_reproject_dma measured NOW: two child runs of this script under
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, the program directly after `--`, as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes; KiB -> bytes; FETCH_SIZE doubled on gfx950).  The caller has released its
@@ -234,6 +234,8 @@ def measure_traffic(workload, timeout_s=150):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
+    if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
+        return None, "this run is itself being profiled (rocprofiler is preloaded): no nested counter passes"
     out = {}
     tmp = tempfile.mkdtemp(prefix="pxl_pmc_")
     try:
