@@ -190,3 +190,86 @@ def place_streams(shapes, dtype=torch.float64, device="cuda", headroom_gib=144, 
     info = {"arena": arena, "allocation_GiB": round(total / GiB, 1), "buffers": where}
     info.update(cinfo)
     return out, info
+
+
+def _split_of(labels):
+    """(majority label, share of the windows NOT carrying it)."""
+    from collections import Counter
+    c = Counter(labels)
+    major, n = c.most_common(1)[0]
+    return major, 1.0 - n / len(labels)
+
+
+def place_pair_compact(src_shape, dst_shape, dtype=torch.float64, device="cuda", budget_gib=200, min_minor_share=0.25, max_tries=40):
+    """The same goal as place_pair -- a destination whose pages lie in two memory classes, a source in another class if there is
+    one -- WITHOUT keeping any head-room: the destination is allocated on its own, its classes are mapped with the store probe,
+    and while it lies inside one class (or has less than `min_minor_share` of its windows in a second one) it is kept as ballast
+    and the next one is tried -- consecutive allocations walk through the device's memory and reach a class boundary within
+    64-96 GiB.  The ballast is returned to the driver before the function returns: afterwards exactly the two maps are allocated.
+    The same topology probe, the same fixed acceptance rule; nothing about the caller's workload is timed.  Returns
+    (src zero-filled, dst, info); falls back to the last candidate (and says so) when the budget runs out."""
+    import math
+    dev = torch.device(device)
+    esz = torch.empty((), dtype=dtype).element_size()
+    ns, nd = math.prod(src_shape), math.prod(dst_shape)
+    ballast, tried = [], []
+    held = 0
+    dst = None
+    dst_labels = None
+    note = None
+    with torch.cuda.device(dev):
+        if nd * esz < 3 * GiB:
+            dst = torch.empty(nd, dtype=dtype, device=dev)
+            note = "destination below 3 GiB: plain allocation"
+        while dst is None:
+            cand = torch.empty(nd, dtype=dtype, device=dev)
+            offs, labels, cinfo = map_classes(cand, step_gib=1)
+            major, minor_share = _split_of(labels)
+            tried.append(round(minor_share, 2))
+            free, _t = torch.cuda.mem_get_info(dev)
+            if minor_share >= min_minor_share:
+                dst, dst_labels = cand, labels
+                note = "destination in two classes (%.0f %% of its windows in the second) after %d allocation(s)" % (100 * minor_share, len(tried))
+            elif len(tried) >= max_tries or held + nd * esz > budget_gib * GiB or free < nd * esz + ns * esz + 8 * GiB:
+                dst, dst_labels = cand, labels
+                note = "no two-class destination within the budget (%d allocations): the last candidate, %.0f %% in a second class" % (len(tried), 100 * minor_share)
+            else:
+                ballast.append(cand)
+                held += nd * esz
+        # the source: prefer an allocation none of whose windows shares a class with the destination
+        src = None
+        src_note = "plain"
+        sballast = []
+        if dst_labels is not None and ns * esz >= GiB:
+            base_d = dst.data_ptr()
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            thr = 2.0 * GiB / 6.25e6
+            # one reference window of the destination per class it has
+            refs = {}
+            for k, lab in enumerate(dst_labels):
+                refs.setdefault(lab, k)
+            sheld = 0
+            while True:
+                cand = torch.empty(ns, dtype=dtype, device=dev)
+                shares = []
+                for lab, k in refs.items():
+                    us = C.c_float()
+                    _lib.check(_lib.load().pxl_mem_probe_pair(C.c_void_p(cand.data_ptr()), C.c_void_p(base_d + k * GiB), GiB, 3, C.byref(us), stream))
+                    shares.append(us.value > thr)              # True: same class as that part of the destination
+                free, _t = torch.cuda.mem_get_info(dev)
+                if not any(shares):
+                    src, src_note = cand, "source in a class the destination does not touch"
+                    break
+                if free < ns * esz + 8 * GiB or sheld + ns * esz > budget_gib * GiB:
+                    src, src_note = cand, "source shares a class with the destination (no other class within the budget)"
+                    break
+                sballast.append(cand)
+                sheld += ns * esz
+        if src is None:
+            src = torch.empty(ns, dtype=dtype, device=dev)
+        del ballast, sballast
+        torch.cuda.empty_cache()
+    src = src.view(tuple(src_shape))
+    dst = dst.view(tuple(dst_shape))
+    src.zero_()
+    return src, dst, {"placement": note, "source": src_note, "candidates_minor_share": tried, "allocation_GiB": round((ns + nd) * esz / GiB, 1)}

@@ -80,3 +80,20 @@ def test_place_streams(pj, dev):
     ra0, dec0 = pj.posmap(shape, wcs, device=dev)
     torch.cuda.synchronize()
     assert torch.equal(ra.view(torch.int64), ra0.data.view(torch.int64)) and torch.equal(dec.view(torch.int64), dec0.data.view(torch.int64))
+
+
+def test_place_pair_compact(pj, dev):
+    """The head-room-free variant: after it returns exactly the two maps are allocated, they are disjoint and usable, and the
+    record says how many candidates were tried and how the destination is split over classes."""
+    torch.cuda.empty_cache()
+    before = torch.cuda.memory_reserved(dev)
+    sshape, dshape = (1, 5400, 21600), (1, 10801, 43200)          # 0.87 GiB source, 3.48 GiB destination
+    src, dst, info = pj.place_pair_compact(sshape, dshape, device=dev, budget_gib=40)
+    assert tuple(src.shape) == sshape and tuple(dst.shape) == dshape and float(src.abs().max()) == 0.0
+    grown = torch.cuda.memory_reserved(dev) - before
+    # no ballast left behind: every rejected candidate is a destination-sized (3.5 GiB) allocation; allow the allocator's own slack
+    assert grown <= (src.numel() + dst.numel()) * 8 + (3 << 29), grown
+    assert len(info["candidates_minor_share"]) >= 1 and "destination" in info["placement"]
+    dst.fill_(1.0)
+    src.fill_(2.0)
+    assert float(dst.min()) == 1.0 and float(src.max()) == 2.0

@@ -1,8 +1,5 @@
 #!/bin/bash
-R=$(pwd)
-cd /tmp && export TMPDIR=/tmp
-for mode in 0 1; do
-  rm -rf $R/gpurun_out/uw_$mode; mkdir -p $R/gpurun_out/uw_$mode
-  PXL_UNWIND_MSPACE=$mode rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/uw_$mode -- python3 $R/tools/prof_unwind.py > /dev/null 2>&1
-  echo "PXL_UNWIND_MSPACE=$mode"; grep -h "k_unwind\|k_scan_wsums" $R/gpurun_out/uw_$mode/*/*kernel_stats.csv | cut -c1-160
+python -m pytest tests/test_gpu_placement.py -x -q 2>&1 | tail -25
+for k in 1 2; do
+    python tools/tune_reproject.py --workload cfg3 --rounds 5 --place-compact "" "flags=64" 2>&1 | grep -v amdgpu.ids | grep -v "^workload" | sed "s/^/compact cfg3: /"
 done
