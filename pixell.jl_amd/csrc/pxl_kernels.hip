@@ -117,6 +117,7 @@ struct pxl_reproject_plan {
     int dxpos;
     int flags;
     int ns, pf;
+    int nt;            // non-temporal stores (LDS-DMA kernel, full tiles)
     int64_t xchunk;
     double* zero_page;
     bool staged_ok;
@@ -635,6 +636,10 @@ int pxl_reproject_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[
     if (pl->ns > 64) pl->ns = 64;
     pl->xchunk = env_int("PXL_REPROJECT_XCHUNK", 0);
     pl->pf = env_int("PXL_REPROJECT_PF", 3);
+    // non-temporal stores keep the column tables in the L2 (pxl_reproject_dma.h).  Measured (profiles/r03_tune_nt.txt): +0.5-0.7 % on
+    // the 22 GB same-resolution IQU launch and +1.5 % when down-sampling 2x, but -1.7 % at 2x refinement and -2.4 ... -5 % on
+    // launches of a few GB (a 1/8 strip, the 1' map), whose tables stay in the L2 anyway: -1 = by launch size at execute time
+    pl->nt = env_int("PXL_REPROJECT_NT", sx > 0.55 ? -1 : 0);
     if (pl->pf < 0) pl->pf = 0;
     const int max_seg = PXL_MAXCH * 128;
     auto seg_for = [&](int pairs) -> int64_t {
@@ -766,6 +771,7 @@ static int reproject_rows_impl(pxl_reproject_plan* pl, const void* src, void* ds
         // LDS-DMA fast path; shrink the ring if it would not fit a CU's LDS comfortably
         const size_t esz = f32 ? 4 : 8;
         p.ns = pl->ns; p.pf = pl->pf; p.zero_page = pl->zero_page;
+        p.nt = pl->nt >= 0 ? pl->nt : ((double)nr * (double)pl->nxo * (double)pl->nc * (f32 ? 4.0 : 8.0) >= 12e9 ? 1 : 0);
         while ((size_t)p.ns * p.seg * esz > 17 * 1024 && p.ns > 4) p.ns >>= 1;    // keep >= 9 waves per CU
         size_t dma_lds = (size_t)p.ns * (size_t)p.seg * esz;
         const int nch = (p.seg + cw - 1) / cw;

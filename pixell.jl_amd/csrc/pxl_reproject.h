@@ -43,6 +43,7 @@ struct ReprojParams {
     int32_t flags;         // tuning/diagnostics: 1 = skip source loads, 2 = skip stores, 4 = no XCD remap, 8 / 16 = tile order 1 / 2 of xcd_tile, 64 = stores only
     // LDS-DMA kernel only
     int32_t ns, pf;        // ring slots (power of two), prefetch distance in output rows
+    int32_t nt;            // non-temporal stores in full tiles
     const double* zero_page;   // 16 bytes of zeros in device memory
 };
 

@@ -268,8 +268,9 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
     // FAST: a tile with every lane inside the map, 16-byte stores and no diagnostics flag -- the stores are unconditional (no
     // exec masking, no flag tests: a third of the loop's scalar instructions), and each of them is certain to issue, so they are
     // counted for the exact waits.  Edge tiles and the diagnostic launches take the general form.
-    auto row_loop = [&](auto fast_tag) {
+    auto row_loop = [&](auto fast_tag, auto nt_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;
+    constexpr bool NT = decltype(nt_tag)::value;
     int th = INT32_MIN / 2;                                     // no row interpolated yet
     for (int rr = 0; rr < nrows; ++rr) {
         const int t0 = __builtin_amdgcn_readlane(my_t0, rr);
@@ -311,7 +312,11 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
 #pragma unroll
             for (int e = 0; e < EPL; ++e) v[e] = (T)(wa * hA[q][e] + wb * hB[q][e]);
             T* o = orow + q * CW;
-            if (FAST) *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(v);
+            if (FAST) {
+                typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+                if (NT) __builtin_nontemporal_store(*reinterpret_cast<const u4v*>(v), reinterpret_cast<u4v*>(o));
+                else *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(v);
+            }
             else if (p.flags & 2) { if (v[0] == (T)1.2345e30) o[0] = v[1]; }       // diagnostics: keep v live, never store
             else if (vec_store) { if (act[q][0]) *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(v); }
             else {
@@ -323,8 +328,14 @@ __global__ __launch_bounds__(64) void k_reproject_dma(ReprojParams p) {
         orow += p.nxo;
     }
     };
-    if (vec_store && (c0 + TW <= p.nxo) && p.flags == 0) row_loop(std::true_type{});
-    else row_loop(std::false_type{});
+    // Non-temporal stores (p.nt, chosen at plan creation): the output then streams through the L2 without evicting the column
+    // tables that every tile re-reads -- with ordinary stores those re-reads miss the L2 and show up as 3-6 % of extra FETCH_SIZE
+    // (1.45 GB per launch of the IQU map; profiles/r03_fetch_by_variant_cfg3.txt) -- worth 0.7 % on the same-resolution IQU map;
+    // the 2x refinement is 1.7 % slower with them and keeps ordinary stores.
+    if (vec_store && (c0 + TW <= p.nxo) && p.flags == 0) {
+        if (p.nt) row_loop(std::true_type{}, std::true_type{});
+        else row_loop(std::true_type{}, std::false_type{});
+    } else row_loop(std::false_type{}, std::false_type{});
 }
 
 template <typename T>
