@@ -170,7 +170,7 @@ def place_buffers(sh, candidates, dev, keep="first", arena=False):
                 src, dst, hold = sh.alloc_pair()
                 pinfo = {"placement": "place_pair FAILED (%s): plain allocation, destination above the source" % type(e).__name__,
                          "allocation_GiB": None, "classes": None, "class_runs_label_from_to_GiB": None, "probe_us_same_class": None,
-                         "probe_us_different_classes": None, "src_offset_GiB": None, "dst_offset_GiB": None}
+                         "probe_us_different_classes": None, "src_offset_GiB": None, "dst_offset_GiB": None, "source": None}
         elif arena:       # one allocation, destination above the source (sharding.alloc_pair: a fixed policy, nothing probed)
             src, dst, hold = sh.alloc_pair()
             holds.append(hold)
@@ -804,7 +804,7 @@ def variant(a, dev):
            "steps": a.steps, "check": r["check"]}
     al = r["config"]["buffer_placement"]["allocation"]
     if isinstance(al, dict):
-        out.update({"placement": al["placement"], "allocation_GiB": al["allocation_GiB"], "classes": al["classes"],
+        out.update({"placement": al["placement"], "source": al.get("source"), "allocation_GiB": al["allocation_GiB"], "classes": al["classes"],
                     "class_runs_label_from_to_GiB": al["class_runs_label_from_to_GiB"], "probe_us_same_class": al["probe_us_same_class"],
                     "probe_us_different_classes": al["probe_us_different_classes"]})
     else:

@@ -74,6 +74,38 @@ def map_classes(arena: torch.Tensor, step_gib=2, window_gib=1):
     return offs, labels, {"classes": len(refs), "probes": nprobes, "probe_us_same_class": round(hi, 1), "probe_us_different_classes": round(lo, 1)}
 
 
+def _separate_in_other_class(nelem, dtype, dev, ref_ptrs, budget_bytes):
+    """A separate allocation of `nelem` elements none of whose first GiB shares a class with the 1 GiB reference windows at
+    `ref_ptrs` (candidates that do are held as ballast while the search goes on, and freed before returning), or None when none
+    turns up within the budget / the free memory."""
+    esz = torch.empty((), dtype=dtype).element_size()
+    if nelem * esz < GiB:
+        return None, 0
+    thr = 2.0 * GiB / 6.25e6
+    ballast, held, found = [], 0, None
+    with torch.cuda.device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        while True:
+            free, _t = torch.cuda.mem_get_info(dev)
+            if free < nelem * esz + 8 * GiB or held + nelem * esz > budget_bytes:
+                break
+            cand = torch.empty(nelem, dtype=dtype, device=dev)
+            same = False
+            for rp in ref_ptrs:
+                us = C.c_float()
+                _lib.check(_lib.load().pxl_mem_probe_pair(C.c_void_p(cand.data_ptr()), C.c_void_p(rp), GiB, 3, C.byref(us), stream))
+                same = same or us.value > thr
+            if not same:
+                found = cand
+                break
+            ballast.append(cand)
+            held += nelem * esz
+        tried = len(ballast) + (1 if found is not None else 0)
+        del ballast
+        torch.cuda.empty_cache()
+    return found, tried
+
+
 def place_pair(src_shape, dst_shape, dtype=torch.float64, device="cuda", headroom_gib=144, step_gib=2):
     """(src, dst, info): a zero-filled source and a destination inside one allocation of (pair size + headroom_gib), the
     destination centred on a boundary between two memory classes whenever the allocation contains one with enough room on both
@@ -135,8 +167,25 @@ def place_pair(src_shape, dst_shape, dtype=torch.float64, device="cuda", headroo
         src_off = 0
     assert src_off + bs <= dst_off or dst_off + bd <= src_off
     view = arena.view(dtype)
-    src = view[src_off // esz: src_off // esz + ns].view(tuple(src_shape))
     dst = view[dst_off // esz: dst_off // esz + nd].view(tuple(dst_shape))
+    src = None
+    src_how = "inside the allocation"
+    if best is not None and best[0] >= min(bd // 8, 1 * GiB):
+        ks = [k for k in range(len(offs)) if offs[k] + GiB > src_off and offs[k] < src_off + bs]
+        if any(labels[k] in dst_labels for k in ks):
+            # the allocation holds no third class with room for the source (it would share a class with half of the destination:
+            # 3-4 % on the 2x refinement): look for one outside, in a separate allocation
+            refs = {}
+            for k in range(len(offs)):
+                if labels[k] in dst_labels:
+                    refs.setdefault(labels[k], arena.data_ptr() + offs[k])
+            found, tried = _separate_in_other_class(ns, dtype, dev, list(refs.values()), 96 * GiB)
+            if found is not None:
+                src, src_how = found.view(tuple(src_shape)), "a separate allocation in a class the destination does not touch (%d tried)" % tried
+            else:
+                src_how = "inside the allocation, in a class the destination also uses (no third class within reach, %d separate allocations tried)" % tried
+    if src is None:
+        src = view[src_off // esz: src_off // esz + ns].view(tuple(src_shape))
     src.zero_()
     runs = []
     for k in range(len(offs)):
@@ -144,7 +193,7 @@ def place_pair(src_shape, dst_shape, dtype=torch.float64, device="cuda", headroo
             runs.append([labels[k], offs[k] // GiB, offs[k] // GiB])
         runs[-1][2] = offs[k] // GiB + 1
     info = {"arena": arena, "allocation_GiB": round(total / GiB, 1), "src_offset_GiB": round(src_off / GiB, 2),
-            "dst_offset_GiB": round(dst_off / GiB, 2), "placement": how, "class_runs_label_from_to_GiB": runs}
+            "dst_offset_GiB": round(dst_off / GiB, 2), "placement": how, "source": src_how, "class_runs_label_from_to_GiB": runs}
     info.update(cinfo)
     return src, dst, info
 

@@ -48,7 +48,9 @@ def test_map_classes_and_place_pair(pj, O, dev):
     lo_d, hi_d = dst.data_ptr(), dst.data_ptr() + dst.numel() * 8
     assert hi_s <= lo_d or hi_d <= lo_s                                    # disjoint
     a0 = pinfo["arena"].data_ptr()
-    assert a0 <= lo_s and hi_s <= a0 + pinfo["arena"].numel() and a0 <= lo_d and hi_d <= a0 + pinfo["arena"].numel()
+    assert a0 <= lo_d and hi_d <= a0 + pinfo["arena"].numel()
+    # the source is inside the allocation too, unless no third class was there and it was found in a separate allocation
+    assert (a0 <= lo_s and hi_s <= a0 + pinfo["arena"].numel()) or "separate allocation" in pinfo["source"]
     assert float(src.abs().max()) == 0.0
     assert "destination" in pinfo["placement"] and pinfo["classes"] >= 1
     pj.fill_random_(src, 99)
@@ -97,3 +99,20 @@ def test_place_pair_compact(pj, dev):
     dst.fill_(1.0)
     src.fill_(2.0)
     assert float(dst.min()) == 1.0 and float(src.max()) == 2.0
+
+
+def test_separate_allocation_in_another_class(pj, dev):
+    """The fallback place_pair uses when its allocation holds no third class for the source: allocate separately until a candidate
+    is in none of the reference windows' classes (or the budget is spent); nothing may stay allocated but the result."""
+    from pixell_jl_amd import placement as P
+    arena = torch.empty(4 << 30, dtype=torch.uint8, device=dev)
+    torch.cuda.empty_cache()
+    before = torch.cuda.memory_reserved(dev)
+    found, tried = P._separate_in_other_class((3 << 29) // 8, torch.float64, dev, [arena.data_ptr(), arena.data_ptr() + (2 << 30)], 12 << 30)
+    assert tried >= 1
+    grown = torch.cuda.memory_reserved(dev) - before
+    if found is not None:
+        assert found.numel() == (3 << 29) // 8 and grown <= (3 << 29) + (64 << 20)
+        found.fill_(1.0)
+    else:
+        assert grown <= (64 << 20)
