@@ -311,6 +311,10 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if os.environ.get("PXL_BENCH_SHARE_GPU") and args.arena == "placed":
+        # rehearsal: several ranks on ONE device.  The class-aware placement takes an allocation with 144 GiB of head-room per rank,
+        # which ranks sharing a device would fight over; a rehearsal checks the flow, not the rate: plain allocations
+        args.arena = True
 
     # stdout carries exactly one JSON line: libraries (RCCL prints a version banner, gloo its connection notes) write
     # to file descriptor 1 behind Python's back, so everything else is sent to stderr from here on
