@@ -117,6 +117,7 @@ struct pxl_reproject_plan {
     int dxpos;
     int flags;
     int ns, pf;
+    int ring_kb;       // LDS a wave's ring may take (KiB); the ring is halved until it fits
     int nt;            // non-temporal stores (LDS-DMA kernel, full tiles)
     int64_t xchunk;
     double* zero_page;
@@ -630,12 +631,22 @@ int pxl_reproject_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[
     if (pl->rh32 < 1) pl->rh32 = 1;
     if (pl->rh32 > 64) pl->rh32 = 64;
     pl->flags = env_int("PXL_REPROJECT_FLAGS", 0);
-    pl->ns = env_int("PXL_REPROJECT_NS", 8);
+    // ring depth: 8 slots; 4 (twice the resident waves) when the whole source sits in the Infinity Cache, where the latency to hide
+    // is short and occupancy wins (config 2, 4096x2049 -> 2x: 0.089 vs 0.103 ms; profiles/r03_tune_pf2_cfg2.txt).  Larger launches
+    // were measured both ways: the IQU map and its strips lose 1.7-2 % with 4, the 1' single-plane map gains 1.9 %
+    pl->ns = env_int("PXL_REPROJECT_NS", (double)pl->nx * (double)pl->ny * (double)pl->nc * 8.0 <= 128.0 * 1048576.0 ? 4 : 8);
     if (pl->ns < 4) pl->ns = 4;
     while (pl->ns & (pl->ns - 1)) pl->ns &= pl->ns - 1;       // power of two
     if (pl->ns > 64) pl->ns = 64;
     pl->xchunk = env_int("PXL_REPROJECT_XCHUNK", 0);
-    pl->pf = env_int("PXL_REPROJECT_PF", 3);
+    // prefetch distance in OUTPUT rows.  What hides the latency is the number of SOURCE rows in flight, and the ring allows ns - 2 of
+    // them beyond the two being read: at 2x refinement 3 output rows ahead were 1.5 source rows (1.58 ms), 12 are 6 (1.51 ms;
+    // profiles/r03_tune_pf_cfg3.txt); at equal resolution 2 ... 6 measure the same
+    {
+        int want_pf = (int)ceil((pl->ns - 2) / (sy > 0.125 ? sy : 0.125));
+        pl->pf = env_int("PXL_REPROJECT_PF", want_pf < 3 ? 3 : want_pf);
+    }
+    pl->ring_kb = env_int("PXL_REPROJECT_RING_KB", 17);
     // non-temporal stores keep the column tables in the L2 (pxl_reproject_dma.h).  Measured (profiles/r03_tune_nt.txt): +0.5-0.7 % on
     // the 22 GB same-resolution IQU launch and +1.5 % when down-sampling 2x, but -1.7 % at 2x refinement and -2.4 ... -5 % on
     // launches of a few GB (a 1/8 strip, the 1' map), whose tables stay in the L2 anyway: -1 = by launch size at execute time
@@ -772,7 +783,7 @@ static int reproject_rows_impl(pxl_reproject_plan* pl, const void* src, void* ds
         const size_t esz = f32 ? 4 : 8;
         p.ns = pl->ns; p.pf = pl->pf; p.zero_page = pl->zero_page;
         p.nt = pl->nt >= 0 ? pl->nt : ((double)nr * (double)pl->nxo * (double)pl->nc * (f32 ? 4.0 : 8.0) >= 12e9 ? 1 : 0);
-        while ((size_t)p.ns * p.seg * esz > 17 * 1024 && p.ns > 4) p.ns >>= 1;    // keep >= 9 waves per CU
+        while ((size_t)p.ns * p.seg * esz > (size_t)pl->ring_kb * 1024 && p.ns > 4) p.ns >>= 1;   // 17 KiB: >= 9 waves per CU
         size_t dma_lds = (size_t)p.ns * (size_t)p.seg * esz;
         const int nch = (p.seg + cw - 1) / cw;
         if (f32) return launch_reproject_dma_t<float>(pairs, nch, grid, dma_lds, st, p);

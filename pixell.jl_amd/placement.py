@@ -101,6 +101,7 @@ def _separate_in_other_class(nelem, dtype, dev, ref_ptrs, budget_bytes):
             ballast.append(cand)
             held += nelem * esz
         tried = len(ballast) + (1 if found is not None else 0)
+        cand = None                      # the last rejected candidate must not outlive the ballast (empty_cache below returns it)
         del ballast
         torch.cuda.empty_cache()
     return found, tried
