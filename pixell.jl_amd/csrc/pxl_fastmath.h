@@ -1,0 +1,156 @@
+// pxl_fastmath.h -- atan2, asin and rsqrt for the Gnomonic evaluators; included by pxl_kernels.hip and, on the host, by
+// tests/native/fastmath_check.cpp (which measures them against long double libm: tests/test_fastmath.py).
+//
+// Why not the device libm: the Gnomonic evaluators are bound by FP64 instruction issue, and ocml's atan2 / asin / sincos cost
+// well over a hundred wave instructions each (rational kernels with a second division, IEEE divisions and square roots with their
+// scaling steps, selects of 64-bit constants).  sincos stays with the library: a Cody-Waite version written here (three-part pi/2,
+// tail carried into both kernels, 0.78 ulp) measured 9 % slower than ocml's on the device, and a no-reduction fast path for
+// |x| <= pi/4 does not apply to wide patches.
+// The paths that use these functions are tolerance-checked against the oracle (glibc) anyway -- the reference's own bar for its
+// Gnomonic code is an L1 bound against wcslib (test_geometry.jl:116-119) -- so what is needed is a couple of ulp, cheaply:
+//   pxl_fm_atan2   one division (reciprocal seed + two Newton steps), an 11-term polynomial on |t| <= tan(pi/8), two further reduction centres (1/2 and 1) chosen so
+//                  that the reduced angle is at most 0.28 of the result (its error is not amplified); <= 2 ulp measured
+//   pxl_fm_asin    one 13-term polynomial for both halves (|v| <= 1/2 directly, else pi/2 - 2 asin(sqrt((1 - |v|)/2)) with the
+//                  square root's residual carried along); <= 2 ulp measured
+//   pxl_fm_rsqrt   seed + one third-order step; <= 1 ulp
+// Every product-sum is an explicit fma (the translation unit is compiled with -ffp-contract=off).  Coefficients:
+// tools/gen_fastmath_coeffs.py (Chebyshev fits at 60 digits).
+#pragma once
+#include "pxl_fastmath_coeffs.h"
+
+#ifndef PXL_FM_HD
+#define PXL_FM_HD __host__ __device__ inline
+#endif
+
+// a * b + c with c a compile-time constant.  On the device the constant is read from a scalar register pair by a VOP3 fma:
+// left to itself the compiler copies every coefficient into a vector register first (v_mov_b64 + v_fmac per Horner step).
+PXL_FM_HD double pxl_fm_fma_k(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+#else
+    return __builtin_fma(a, b, c);
+#endif
+}
+// a * k + c with k a compile-time constant
+PXL_FM_HD double pxl_fm_kfma(double a, double k, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c));
+    return r;
+#else
+    return __builtin_fma(a, k, c);
+#endif
+}
+
+template <int N>
+PXL_FM_HD double pxl_fm_horner(const double (&c)[N], double z) {
+    double p = c[N - 1];
+#pragma unroll
+    for (int i = N - 2; i >= 0; --i) p = pxl_fm_fma_k(p, z, c[i]);
+    return p;
+}
+
+// the hardware's reciprocal and reciprocal-square-root seeds (v_rcp_f64, v_rsq_f64).  On the host: the exact value cut to 24
+// bits, so that the harness exercises the refinements below with seeds no better than the device's
+#if !defined(__HIP_DEVICE_COMPILE__)
+static inline double pxl_fm_cut24(double v) {
+    unsigned long long b;
+    __builtin_memcpy(&b, &v, 8);
+    b &= ~((1ULL << 29) - 1);
+    __builtin_memcpy(&v, &b, 8);
+    return v;
+}
+#endif
+PXL_FM_HD double pxl_fm_rsq_seed(double w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsq(w);
+#else
+    return pxl_fm_cut24(1.0 / __builtin_sqrt(w));
+#endif
+}
+PXL_FM_HD double pxl_fm_rcp_seed(double w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(w);
+#else
+    return pxl_fm_cut24(1.0 / w);
+#endif
+}
+
+// 1/sqrt(u) for u in [2^-1000, 2^1000] to ~1 ulp: seed y0 (relative error e0 <= 2^-20), then y0 (1 + e/2 + 3 e^2/8), e = 1 - u y0^2
+PXL_FM_HD double pxl_fm_rsqrt(double u) {
+    const double y0 = pxl_fm_rsq_seed(u);
+    const double e = __builtin_fma(-(u * y0), y0, 1.0);
+    return __builtin_fma(y0 * e, __builtin_fma(0.375, e, 0.5), y0);
+}
+
+// atan2(y, x), IEEE special cases included (signed zeros, infinities, NaN).  Branch-free, and the choices are made with 0 / 1
+// flags in arithmetic (flag * constant is exact) rather than with selects of 64-bit constants, which would each cost two
+// v_cndmask and a vector register pair per constant.
+PXL_FM_HD double pxl_fm_atan2(double y, double x) {
+    constexpr double Q[PXL_FM_ATAN_Q_N] = PXL_FM_ATAN_Q;
+    const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
+    const double fs = (ay > ax) ? 1.0 : 0.0;                     // swap: the angle is measured from the y axis
+    double mx = __builtin_fmax(ax, ay), mn = __builtin_fmin(ax, ay);
+    const bool mxinf = mx == __builtin_inf();
+    mn = mxinf ? ((mn == __builtin_inf()) ? 1.0 : 0.0) : mn;
+    mx = mxinf ? 1.0 : mx;
+    // bring the pair into [2^-764, 2^764] (exact): the sums below cannot overflow, nothing is subnormal, and the quotient can be
+    // formed from the reciprocal seed without the scaling steps of an IEEE division
+    const double sc = mx > 0x1p+764 ? 0x1p-260 : (mx < 0x1p-764 ? 0x1p+260 : 1.0);
+    mn *= sc;
+    mx *= sc;
+    // atan(mn / mx) = o + atan(t) with the centre c (o = atan c) nearest below the ratio among 0, 1/2, 1:
+    //   t = (mn - c mx) / (mx + c mn);  the numerators mn - mx/2 and mn - mx are exact (Sterbenz) in their intervals
+    const bool i1 = mn > PXL_FM_TAN_PIO8 * mx;          // ratio above tan(pi/8)
+    const bool i2 = mn > 0.75 * mx;                     // ratio in (3/4, 1]: centre 1
+    const double f2 = i2 ? 1.0 : 0.0;
+    const double f1 = (i1 && !i2) ? 1.0 : 0.0;          // ratio in (tan(pi/8), 3/4]: centre 1/2
+    const double c = pxl_fm_kfma(f1, 0.5, f2);
+    const double o_hi = pxl_fm_kfma(f1, PXL_FM_ATAN_HALF_HI, f2 * PXL_FM_PIO4_HI);
+    const double o_lo = pxl_fm_kfma(f1, PXL_FM_ATAN_HALF_LO, f2 * PXL_FM_PIO4_LO);
+    const double num = __builtin_fma(-c, mx, mn);
+    double den = __builtin_fma(c, mn, mx);
+    den = (den == 0.0) ? 1.0 : den;                     // atan2(+-0, +-0): t = 0
+    double rd = pxl_fm_rcp_seed(den);
+    rd = __builtin_fma(__builtin_fma(-den, rd, 1.0), rd, rd);
+    rd = __builtin_fma(__builtin_fma(-den, rd, 1.0), rd, rd);
+    const double t0 = num * rd;
+    const double t = __builtin_fma(__builtin_fma(-den, t0, num), rd, t0);      // num / den to <= 1 ulp
+    const double z = t * t;
+    const double r = __builtin_fma(t * z, pxl_fm_horner(Q, z), t);         // atan(t)
+    double a = o_hi + (r + o_lo);                       // the octant's angle, in [0, pi/4]
+    // octant -> quadrant: swap mirrors about pi/4 (pi/2 - a), a negative x about pi/2 (pi - a): K + (+-a + K_lo), K = flag * constant
+    const double fx = __builtin_signbit(x) ? 1.0 : 0.0;
+    a = pxl_fm_kfma(fs, PXL_FM_PIO2_1, pxl_fm_kfma(fs, PXL_FM_PIO2_2, __builtin_fma(-2.0, fs, 1.0) * a));
+    a = pxl_fm_kfma(fx, PXL_FM_PI_HI, pxl_fm_kfma(fx, PXL_FM_PI_LO, __builtin_fma(-2.0, fx, 1.0) * a));
+    a = __builtin_copysign(a, y);
+    return (x != x || y != y) ? x + y : a;
+}
+
+// asin(v); NaN outside [-1, 1]
+PXL_FM_HD double pxl_fm_asin(double v) {
+    constexpr double R[PXL_FM_ASIN_R_N] = PXL_FM_ASIN_R;
+    const double av = __builtin_fabs(v);
+    const bool big = av > 0.5;
+    // big: asin(av) = pi/2 - 2 asin(sqrt(w)), w = (1 - av) / 2 (exact for av in (1/2, 1], and then in [2^-54, 1/4) or 0)
+    const double w = __builtin_fma(-0.5, av, 0.5);
+    // sqrt(w) = b + blo: one Goldschmidt step from the seed, then two corrections by the exact residual w - s^2
+    const double y0 = pxl_fm_rsq_seed(w + 0x1p-200);                       // w itself for w >= 2^-54; finite for w = 0 (|v| = 1)
+    const double h = 0.5 * y0;
+    const double s0 = w * y0;
+    const double s1 = __builtin_fma(s0, __builtin_fma(-s0, h, 0.5), s0);
+    const double b1 = __builtin_fma(__builtin_fma(-s1, s1, w), h, s1);
+    const double blo = __builtin_fma(-b1, b1, w) * h;
+    const double z = big ? w : v * v;
+    const double b = big ? b1 : av;
+    const double p = (b * z) * pxl_fm_horner(R, z);                        // asin(b) - b
+    // pi/2 - 2 (b + blo + p): the leading difference with its rounding error (fast two-sum: pi/2 >= 2 b)
+    const double b2 = b1 + b1;
+    const double u = PXL_FM_PIO2_1 - b2;
+    const double uerr = (PXL_FM_PIO2_1 - u) - b2;
+    const double rbig = u + (uerr - (((blo + p) + (blo + p)) - PXL_FM_PIO2_2));
+    const double rsmall = av + p;
+    return __builtin_copysign(big ? rbig : rsmall, v);
+}

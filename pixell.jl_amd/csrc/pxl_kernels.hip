@@ -80,6 +80,7 @@ static int env_int(const char* name, int dflt) {
 #include "pxl_elementwise.h"
 #include "pxl_unwrap.h"
 #include "pxl_maps.h"
+#include "pxl_fastmath.h"
 #include "pxl_tan.h"
 #include "pxl_reproject.h"
 #include "pxl_reproject_dma.h"
@@ -546,9 +547,10 @@ int pxl_posmap_tan_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64_t r
     if (nrows == 0) return PXL_OK;
     if (!ra || !dec) return fail(PXL_EINVAL, "posmap_tan: null output");
     const int64_t nchunk = (shape[0] + 511) / 512;                 // 512 RA pixels per block
-    if (nchunk * nrows > 0x7fffffffLL) return fail(PXL_EINVAL, "posmap_tan: map too large for one launch");
+    const int64_t nrb = (nrows + PXL_TAN_ROWS - 1) / PXL_TAN_ROWS;   // PXL_TAN_ROWS rows per block
+    if (nchunk * nrb > 0x7fffffffLL) return fail(PXL_EINVAL, "posmap_tan: map too large for one launch");
     const bool vec = (shape[0] % 2 == 0) && ((((uintptr_t)ra | (uintptr_t)dec) & 15) == 0);
-    const dim3 grid((unsigned)(nchunk * nrows));
+    const dim3 grid((unsigned)(nchunk * nrb));
     if (vec) hipLaunchKernelGGL((k_posmap_tan<true>), grid, dim3(256), 0, (hipStream_t)stream, tan_setup(*wcs), shape[0], row0, nrows, nchunk, ra, dec);
     else     hipLaunchKernelGGL((k_posmap_tan<false>), grid, dim3(256), 0, (hipStream_t)stream, tan_setup(*wcs), shape[0], row0, nrows, nchunk, ra, dec);
     return check_launch("k_posmap_tan");

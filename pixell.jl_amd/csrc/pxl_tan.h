@@ -4,11 +4,12 @@
 // ------------------------------------------------------------------------------------------------
 // Gnomonic (A16), tan_proj.jl:44-75
 // ------------------------------------------------------------------------------------------------
-// These are tolerance-checked paths (FP64 transcendentals: device libm vs glibc), held to the reference's own bar for
+// These are tolerance-checked paths (FP64 transcendentals: pxl_fastmath.h's atan2 / asin / rsqrt, <= 1.5 ulp, and the device
+// library's sincos, vs glibc), held to the reference's own bar for
 // its fast Gnomonic code against wcslib: sum |difference| < 1e-9 over the 1827 x 1825 posmap (test_geometry.jl:116-119).
 //
 // sky2pix keeps the reference's operations one for one; each angle's sine and cosine come from ONE sincos (one
-// argument reduction instead of two) and the loop-invariant scale / unit is divided once on the host (a correctly
+// argument reduction instead of two; the library's: a sincos of our own, with or without reduction, measured slower -- DESIGN 4b) and the loop-invariant scale / unit is divided once on the host (a correctly
 // rounded quotient either way).
 //
 // pix2sky is evaluated in an algebraically equal form without the intermediate angles.  The reference
@@ -21,7 +22,7 @@
 // i.e. one rsqrt, one atan2 and one asin instead of sqrt, atan, two atan2, two sin, two cos and asin.  On the
 // reference's patch the two forms differ by at most one ulp of the angle, 3e-11 (RA) / 6e-11 (DEC) summed over the
 // 3.3 M pixels against the 1e-9 allowed (glibc on both sides; tests/test_gpu_parity.py holds the device to the bound).
-struct TanParams { double scale, unit, a0, d0, sd0, cd0, cpx, cpy, su; };
+struct TanParams { double scale, unit, a0, d0, sd0, cd0, cpx, cpy, su, uos; };
 static TanParams tan_setup(const pxl_car_wcs& w) {
     TanParams t;
     t.scale = 1.0 / w.cdelt[0];
@@ -31,6 +32,8 @@ static TanParams tan_setup(const pxl_car_wcs& w) {
     t.sd0 = sin(t.d0); t.cd0 = cos(t.d0);
     t.cpx = w.crpix[0]; t.cpy = w.crpix[1];
     t.su = t.scale / t.unit;                 // the left-to-right head of `scale / unit / (...)`, tan_proj.jl:50
+    t.uos = t.unit / t.scale;                // pix2sky: `(crpix - i) * unit / scale` (tan_proj.jl:62-63) as one multiplication -- a
+                                             // second rounding of X at most, inside the tolerance these paths are held to
     return t;
 }
 __device__ inline void tan_sky2pix(const TanParams& t, double a, double d, double* x, double* y) {
@@ -47,20 +50,25 @@ __device__ inline void tan_sky2pix(const TanParams& t, double a, double d, doubl
 // the row-dependent half of pix2sky: Y and the two combinations of it that every pixel of a row shares
 struct TanRow { double Y2, den, num; };
 __device__ inline TanRow tan_row(const TanParams& t, double j) {
-    const double Y = (t.cpy - j) * t.unit / t.scale;
+    const double Y = (t.cpy - j) * t.uos;
     return TanRow{Y * Y, t.sd0 * Y + t.cd0, t.sd0 - t.cd0 * Y};
 }
+__device__ inline void tan_pix2sky_xrow(const TanParams& t, const TanRow& r, double X, double XX, double* a, double* d) {
+    const double rs = pxl_fm_rsqrt(1.0 + (XX + r.Y2));
+    *a = t.a0 + pxl_fm_atan2(-X, r.den);
+    *d = pxl_fm_asin(r.num * rs);
+}
 __device__ inline void tan_pix2sky_row(const TanParams& t, const TanRow& r, double i, double* a, double* d) {
-    const double X = (t.cpx - i) * t.unit / t.scale;
-    const double rs = rsqrt(1.0 + (X * X + r.Y2));
-    *a = t.a0 + atan2(-X, r.den);
-    *d = asin(r.num * rs);
+    const double X = (t.cpx - i) * t.uos;
+    tan_pix2sky_xrow(t, r, X, X * X, a, d);
 }
 __device__ inline void tan_pix2sky(const TanParams& t, double i, double j, double* a, double* d) {
     tan_pix2sky_row(t, tan_row(t, j), i, a, d);
 }
 
-// Two points per lane, 16-byte accesses (VEC: all four arrays 16-byte aligned), one contiguous chunk per block.
+// Two points per lane, 16-byte accesses (VEC: all four arrays 16-byte aligned), one contiguous chunk per block.  (A block that
+// takes eight consecutive chunks, with the next chunk's loads issued before the arithmetic of the current one, measured 3-7 %
+// slower, A/B in one process: profiles/r03_ab_tan_trips.jsonl.)
 template <bool VEC, bool INVERSE>
 __global__ __launch_bounds__(256) void k_tan_points(TanParams t, int64_t n, const double* __restrict__ in1,
                                                     const double* __restrict__ in2, double* __restrict__ out1,
@@ -93,27 +101,35 @@ __global__ __launch_bounds__(256) void k_tan_points(TanParams t, int64_t n, cons
     }
 }
 
-// posmap of a Gnomonic map: a block covers 512 adjacent RA pixels of one row (two per lane, 16-byte stores when the
-// row pitch allows); the row's share of the arithmetic is computed once per lane.
+// posmap of a Gnomonic map: a block covers 512 adjacent RA pixels (two per lane, 16-byte stores when the row pitch allows) of
+// PXL_TAN_ROWS consecutive rows; the column's share of the arithmetic and the constants are set up once per block (4-7 % faster
+// than one row per block, same A/B).
+#define PXL_TAN_ROWS 8
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_posmap_tan(TanParams t, int64_t nx, int64_t row0, int64_t nrows, int64_t nchunk,
                                                     double* __restrict__ ra, double* __restrict__ dec) {
     const int64_t b = blockIdx.x;
-    const int64_t jr = b / nchunk;
-    if (jr >= nrows) return;
-    const int64_t i = ((b - jr * nchunk) * blockDim.x + threadIdx.x) * 2;      // 0-based column of the lane's first pixel
+    const int64_t jb = (b / nchunk) * PXL_TAN_ROWS;                             // first row of the block (within the request)
+    const int64_t i = ((b % nchunk) * blockDim.x + threadIdx.x) * 2;            // 0-based column of the lane's first pixel
     if (i >= nx) return;
-    const TanRow r = tan_row(t, (double)(row0 + jr + 1));
-    double a[2], d[2];
     const bool two = i + 1 < nx;
-    tan_pix2sky_row(t, r, (double)(i + 1), &a[0], &d[0]);
-    if (two) tan_pix2sky_row(t, r, (double)(i + 2), &a[1], &d[1]);
-    const int64_t o = jr * nx + i;
-    if (VEC && two) {
-        *reinterpret_cast<double2*>(ra + o) = make_double2(a[0], a[1]);
-        *reinterpret_cast<double2*>(dec + o) = make_double2(d[0], d[1]);
-    } else {
-        ra[o] = a[0]; dec[o] = d[0];
-        if (two) { ra[o + 1] = a[1]; dec[o + 1] = d[1]; }
+    const double X0 = (t.cpx - (double)(i + 1)) * t.uos, X1 = (t.cpx - (double)(i + 2)) * t.uos;
+    const double XX0 = X0 * X0, XX1 = X1 * X1;
+#pragma unroll 1
+    for (int q = 0; q < PXL_TAN_ROWS; ++q) {
+        const int64_t jr = jb + q;
+        if (jr >= nrows) break;
+        const TanRow r = tan_row(t, (double)(row0 + jr + 1));
+        double a[2], d[2];
+        tan_pix2sky_xrow(t, r, X0, XX0, &a[0], &d[0]);
+        tan_pix2sky_xrow(t, r, X1, XX1, &a[1], &d[1]);
+        const int64_t o = jr * nx + i;
+        if (VEC && two) {
+            *reinterpret_cast<double2*>(ra + o) = make_double2(a[0], a[1]);
+            *reinterpret_cast<double2*>(dec + o) = make_double2(d[0], d[1]);
+        } else {
+            ra[o] = a[0]; dec[o] = d[0];
+            if (two) { ra[o + 1] = a[1]; dec[o + 1] = d[1]; }
+        }
     }
 }

@@ -1,0 +1,75 @@
+// fastmath_check.cpp -- accuracy of pixell.jl_amd/csrc/pxl_fastmath.h on the host against long double libm (x87: 64-bit
+// significand, i.e. 2^-11 of a double's ulp).  Built and run by tests/test_fastmath.py; prints one JSON object.
+//   g++ -O2 -std=c++17 -ffp-contract=off -I pixell.jl_amd/csrc tests/native/fastmath_check.cpp -o /tmp/fastmath_check
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#define PXL_FM_HD static inline
+#include "pxl_fastmath.h"
+
+static double ulp_of(long double v) {            // spacing of doubles at |v|
+    double d = std::fabs((double)v);
+    if (d < 2.2250738585072014e-308) return 4.9406564584124654e-324;
+    int e;
+    std::frexp(d, &e);
+    return std::ldexp(1.0, e - 53);
+}
+static double err_ulp(double got, long double want) {
+    if (std::isnan(got) || std::isnan((double)want)) return (std::isnan(got) && std::isnan((double)want)) ? 0.0 : 1e30;
+    return (double)(fabsl((long double)got - want) / (long double)ulp_of(want));
+}
+static bool same_bits(double a, double b) { return std::memcmp(&a, &b, 8) == 0 || (std::isnan(a) && std::isnan(b)); }
+
+int main(int argc, char** argv) {
+    const long n = argc > 1 ? atol(argv[1]) : 4000000;
+    std::mt19937_64 rng(20261004);
+    std::uniform_real_distribution<double> U(0.0, 1.0);
+    double e_atan2 = 0, e_asin = 0;
+    double w_atan2[2] = {0, 0}, w_asin = 0, e_rsqrt = 0, w_rsqrt = 0;
+    for (long k = 0; k < n; ++k) {
+        // atan2: angles uniform on the circle (and clustered at the octant / interval boundaries), radii over 600 binades
+        double ang = (k & 1) ? (U(rng) * 2 - 1) * M_PI : std::round(U(rng) * 64) * (M_PI / 32) + (U(rng) - 0.5) * 1e-6;
+        if ((k & 7) == 3) ang = std::atan(0.75) + (U(rng) - 0.5) * 1e-9;
+        if ((k & 7) == 5) ang = M_PI / 8 + (U(rng) - 0.5) * 1e-9;
+        double rad = std::exp2((U(rng) - 0.5) * 600);
+        double y = rad * std::sin(ang), x = rad * std::cos(ang);
+        double e = err_ulp(pxl_fm_atan2(y, x), atan2l((long double)y, (long double)x));
+        if (e > e_atan2) { e_atan2 = e; w_atan2[0] = y; w_atan2[1] = x; }
+        // asin: uniform, clustered at 0, 1/2 and 1
+        double v = U(rng) * 2 - 1;
+        if ((k & 3) == 1) v = std::copysign(0.5 + (U(rng) - 0.5) * 1e-3, v);
+        if ((k & 3) == 2) v = std::copysign(1.0 - U(rng) * U(rng) * 1e-2, v);
+        if ((k & 15) == 7) v = std::exp2(-U(rng) * 60) * (v < 0 ? -1 : 1);
+        e = err_ulp(pxl_fm_asin(v), asinl((long double)v));
+        if (e > e_asin) { e_asin = e; w_asin = v; }
+        // rsqrt: the evaluators call it on 1 + X^2 + Y^2; here over 200 binades
+        {
+            double uu = std::exp2((U(rng) - 0.5) * 200);
+            if (k & 1) uu = 1.0 + U(rng) * 3;
+            double er = err_ulp(pxl_fm_rsqrt(uu), 1.0L / sqrtl((long double)uu));
+            if (er > e_rsqrt) { e_rsqrt = er; w_rsqrt = uu; }
+        }
+    }
+    // special cases: bit-for-bit what libm returns
+    const double inf = INFINITY, nan = NAN;
+    const double sp[] = {0.0, -0.0, 1.0, -1.0, inf, -inf, nan, 5e-324, -5e-324, 1e308, -1e308, 0.5, 0.75, 2.0};
+    int special_bad = 0;
+    for (double y : sp)
+        for (double x : sp) {
+            double g = pxl_fm_atan2(y, x), w = std::atan2(y, x);
+            if (!(same_bits(g, w) || err_ulp(g, atan2l((long double)y, (long double)x)) <= 1.0) || std::signbit(g) != std::signbit(w)) {
+                if (!(std::isnan(g) && std::isnan(w))) { ++special_bad; fprintf(stderr, "atan2(%g, %g) = %a, libm %a\n", y, x, g, w); }
+            }
+        }
+    for (double v : {0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 1.0000000000000002, -1.5, (double)inf, (double)nan, 5e-324, 1e-200}) {
+        double g = pxl_fm_asin(v), w = std::asin(v);
+        if (!(same_bits(g, w) || err_ulp(g, asinl((long double)v)) <= 1.0) || (!std::isnan(w) && std::signbit(g) != std::signbit(w))) { ++special_bad; fprintf(stderr, "asin(%g) = %a, libm %a\n", v, g, w); }
+    }
+    printf("{\"samples\": %ld, \"atan2_max_ulp\": %.3f, \"atan2_worst\": [%.17g, %.17g], \"asin_max_ulp\": %.3f, \"asin_worst\": %.17g, "
+           "\"rsqrt_max_ulp\": %.3f, "
+           "\"rsqrt_worst\": %.17g, \"special_bad\": %d}\n",
+           n, e_atan2, w_atan2[0], w_atan2[1], e_asin, w_asin, e_rsqrt, w_rsqrt, special_bad);
+    return 0;
+}

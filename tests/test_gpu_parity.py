@@ -897,6 +897,41 @@ def test_gnomonic_pix2sky_arrays_on_device(pj, O, dev, literals):
     assert np.abs(x.cpu().numpy() - ip).max() < 1e-6 and np.abs(y.cpu().numpy() - jp).max() < 1e-6
 
 
+def test_gnomonic_wide_fields_on_device(pj, O, dev):
+    """The evaluators' own atan2 / asin / sincos / rsqrt (pxl_fastmath.h) across their whole domain on the device: patches centred
+    from pole to pole, points out to ~85 degrees from the centre (every octant of atan2, both halves of asin, several
+    periods of the sincos reduction), against the oracle's glibc at a few ulp of the angle / 1e-9 of a pixel."""
+    rng = np.random.default_rng(23)
+    n = 200001
+    for crval in ((0.0, 0.0), (97.5, -7.5), (-170.0, 45.0), (10.0, 89.9), (200.0, -89.0), (359.0, 60.0), (-720.5, -30.0)):
+        wcs = pj.Gnomonic((-1.0 / 60, 1.0 / 60), (1000.5, 900.5), crval)
+        shape = (2000, 1800)
+        # plane radius r = tan(distance from the centre): up to tan(85 deg) = 11.4 rad = 39 300 pixels of 1 arcmin
+        rad = np.tan(np.radians(rng.uniform(0.0, 85.0, n))) / np.radians(1.0 / 60)
+        phi = rng.uniform(0.0, 2 * np.pi, n)
+        phi[:64] = np.arange(64) * (np.pi / 32)                       # the octant boundaries
+        ip, jp = 1000.5 + rad * np.cos(phi), 900.5 + rad * np.sin(phi)
+        ra, dec = pj.pix2sky((shape, wcs), to_dev(ip, dev), to_dev(jp, dev), safe=False)
+        era, edec = O.pix2sky_tan(wcs, ip, jp)
+        # both sides carry ~1e-16 / cos(dec) of conditioning (the reference's form takes asin / atan2 of direction cosines)
+        tol = 4e-16 * np.abs(era) + 2e-15 / np.maximum(np.cos(edec), 1e-6)
+        assert (np.abs(ra.cpu().numpy() - era) < tol).all()
+        assert (np.abs(dec.cpu().numpy() - edec) < tol).all()
+        x, y = pj.sky2pix((shape, wcs), to_dev(era, dev), to_dev(edec, dev), safe=False)
+        ex, ey = O.sky2pix_tan(wcs, era, edec)
+        r = rad * np.radians(1.0 / 60)             # plane radius; d(pixel)/d(angle) grows like 1 + r^2 towards the horizon
+        tol = 1e-9 + 2e-14 * rad * (1.0 + r * r)
+        assert (np.abs(x.cpu().numpy() - ex) < tol).all() and (np.abs(y.cpu().numpy() - ey) < tol).all()
+    # angles many periods away from the centre, and beyond the fast sincos range (the library path)
+    wcs = pj.Gnomonic((-1.0 / 60, 1.0 / 60), (1000.5, 900.5), (30.0, 20.0))
+    base_ra, base_dec = np.radians(30.0) + rng.uniform(-0.3, 0.3, 4096), np.radians(20.0) + rng.uniform(-0.3, 0.3, 4096)
+    for turns in (1, -3, 1000, 200000):
+        a = base_ra + turns * 2 * np.pi
+        x, y = pj.sky2pix(((2000, 1800), wcs), to_dev(a, dev), to_dev(base_dec, dev), safe=False)
+        ex, ey = O.sky2pix_tan(wcs, a, base_dec)
+        assert np.abs(x.cpu().numpy() - ex).max() < 1e-6 and np.abs(y.cpu().numpy() - ey).max() < 1e-6
+
+
 @pytest.mark.parametrize("f32", [False, True])
 def test_reproject_every_tile_shape(pj, O, dev, f32, monkeypatch):
     """The LDS-DMA kernel is instantiated per (storage type, lane width, 16-byte chunks per source-row segment):
