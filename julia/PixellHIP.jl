@@ -43,13 +43,16 @@ end
 mutable struct HIPArray{T,N} <: AbstractArray{T,N}
     ptr::Ptr{T}
     dims::NTuple{N,Int}
+    parent::Any
     function HIPArray{T,N}(::UndefInitializer, dims::NTuple{N,Int}) where {T,N}
         p = Ref{Ptr{Cvoid}}()
         rc = ccall((:hipMalloc, libhip), Cint, (Ptr{Ptr{Cvoid}}, Csize_t), p, prod(dims) * sizeof(T))
         rc == 0 || error("hipMalloc failed ($rc)")
-        a = new{T,N}(Ptr{T}(p[]), dims)
+        a = new{T,N}(Ptr{T}(p[]), dims, nothing)
         finalizer(x -> ccall((:hipFree, libhip), Cint, (Ptr{Cvoid},), x.ptr), a)
     end
+    # a view into `parent`'s memory (kept alive by the reference; no finalizer of its own): place_pair below
+    HIPArray{T,N}(ptr::Ptr{T}, dims::NTuple{N,Int}, parent) where {T,N} = new{T,N}(ptr, dims, parent)
 end
 HIPArray{T}(u::UndefInitializer, dims::Int...) where {T} = HIPArray{T,length(dims)}(u, dims)
 Base.size(a::HIPArray) = a.dims
@@ -415,6 +418,65 @@ sharded_step!(dst, plan, src, own_rows, sends, recvs, comm::PxlComm) = sharded_s
 comm_destroy(c::PxlComm) = check(ccall((:pxl_comm_destroy, libpixell_hip), Cint, (Ptr{Cvoid},), c.handle))
 comm_backend() = unsafe_string(ccall((:pxl_comm_backend, libpixell_hip), Cstring, ()))
 
+# ---- class-aware placement of a (source, destination) pair (DESIGN.md section 9 item 6; pixell.jl_amd/placement.py is the Python twin).
+# The memory of an allocation falls into three classes; a kernel with several far-apart write fronts (the reprojection: one per
+# XCD) stores at 5.8-6.0 TB/s into one class and at 6.8-7.1 TB/s when its destination straddles two.  `mem_probe_pair` times the
+# 8-front store probe on two windows (it overwrites them with zeros): slow = same class.
+function mem_probe_pair(a::Ptr, b::Ptr; window::Integer=1 << 30, reps::Integer=3)
+    us = Ref{Cfloat}(0)
+    check(ccall((:pxl_mem_probe_pair, libpixell_hip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint, Ptr{Cfloat}, Ptr{Cvoid}),
+                Ptr{Cvoid}(a), Ptr{Cvoid}(b), window, reps, us, NULLSTREAM))
+    return us[]
+end
+
+# class label of every `step`-spaced 1 GiB window of `arena` (labels 1, 2, 3 in order of appearance)
+function map_classes(arena::HIPArray{UInt8,1}; step::Integer=2 << 30, window::Integer=1 << 30)
+    thr = 2.0 * window / 6.25e6                       # microseconds: above = the two windows share a class (~383 vs ~305 us per GiB)
+    offs = collect(0:step:(length(arena) - window))
+    labels = zeros(Int, length(offs)); refs = Int[]    # refs[c] = offset of the first window seen of class c
+    for (k, off) in enumerate(offs)
+        for (c, r) in enumerate(refs)
+            if off == r || mem_probe_pair(arena.ptr + off, arena.ptr + r; window=window) > thr
+                labels[k] = c; break
+            end
+        end
+        if labels[k] == 0
+            push!(refs, off); labels[k] = length(refs)
+        end
+    end
+    return offs, labels
+end
+
+# (src, dst): views of ONE allocation of (pair + headroom) bytes, the destination centred on a boundary between two classes when
+# the allocation has one with room on both sides, the source in windows of a class the destination does not touch when there
+# are any; a plain layout (source first, destination above it) otherwise.  Both are zero-filled by the probe or by hipMemset.
+function place_pair(::Type{T}, src_dims::NTuple{N,Int}, dst_dims::NTuple{M,Int}; headroom::Integer=144 << 30, step::Integer=2 << 30) where {T,N,M}
+    al = 2 << 20
+    bs, bd = cld(prod(src_dims) * sizeof(T), al) * al, cld(prod(dst_dims) * sizeof(T), al) * al
+    arena = HIPArray{UInt8,1}(undef, (bs + bd + headroom,))
+    offs, labels = map_classes(arena; step=step)
+    total = length(arena)
+    src_off, dst_off = 0, bs
+    for k in 2:length(offs)
+        labels[k] == labels[k - 1] && continue
+        cand = (offs[k] - bd ÷ 2) ÷ al * al            # the boundary lies between windows k-1 and k
+        if cand >= 0 && cand + bd <= total
+            dst_off = cand
+            touched = Set(labels[j] for j in eachindex(offs) if offs[j] + (1 << 30) > dst_off && offs[j] < dst_off + bd)
+            clear(o) = all(!(labels[j] in touched) for j in eachindex(offs) if offs[j] + (1 << 30) > o && offs[j] < o + bs)
+            free = [o for o in offs if (o + bs <= dst_off || o >= dst_off + bd) && o + bs <= total && clear(o)]
+            src_off = !isempty(free) ? first(free) : (dst_off >= bs ? 0 : dst_off + bd)
+            src_off + bs <= total || continue
+            break
+        end
+    end
+    ccall((:hipMemset, libhip), Cint, (Ptr{Cvoid}, Cint, Csize_t), arena.ptr + src_off, 0, bs)
+    src = HIPArray{T,N}(Ptr{T}(arena.ptr + src_off), src_dims, arena)
+    dst = HIPArray{T,M}(Ptr{T}(arena.ptr + dst_off), dst_dims, arena)
+    return src, dst
+end
+
+export mem_probe_pair, map_classes, place_pair
 export HIPArray, posmap_device, reproject, reproject_generic, reproject!, ReprojectPlan, sample_bilinear, SamplePairs, HaloXfer, sharded_step!
 export PxlComm, comm_unique_id, comm_init_rank, comm_destroy, comm_backend
 end # module

@@ -134,3 +134,16 @@ end
     ref = read_map(joinpath(@__DIR__, "..", "tests", "golden", "test.fits"))   # the reference's own fixture (test/data/test.fits)
     @test Array(parent(read_map(joinpath(@__DIR__, "..", "tests", "golden", "test.fits"), HIPArray))) == parent(ref)
 end
+
+@testset "class-aware placement of a reprojection pair" begin
+    src, dst = PixellHIP.place_pair(Float64, (21600, 10801), (43200, 21601); headroom=64 << 30)
+    @test size(src) == (21600, 10801) && size(dst) == (43200, 21601) && src.parent === dst.parent
+    lo, hi = minmax(UInt(src.ptr), UInt(dst.ptr))                       # the views do not overlap and lie inside the allocation
+    @test lo + (lo == UInt(src.ptr) ? sizeof(Float64) * prod(size(src)) : sizeof(Float64) * prod(size(dst))) <= hi
+    @test all(==(0.0), Array(src)[1:1000])                              # the source is zero-filled
+    offs, labels = PixellHIP.map_classes(src.parent)
+    @test 1 <= maximum(labels) <= 3                                     # the three memory classes of the part (DESIGN.md section 9 item 6)
+    plan = PixellHIP.ReprojectPlan(fullsky_geometry(deg2rad(1 / 60))..., fullsky_geometry(deg2rad(0.5 / 60))...)
+    PixellHIP.reproject!(dst, plan, src)
+    @test all(==(0.0), Array(dst)[1:1000])
+end
