@@ -27,7 +27,7 @@ __host__ __device__ inline double fmod_pos_try(double x, double y, double ry, bo
     const double ax = fabs(x);
     double q = trunc(ax * ry);
     double r = __builtin_fma(-q, y, ax);
-    q = r < 0.0 ? q - 1.0 : (r >= y ? q + 1.0 : q);
+    q = (q - (r < 0.0 ? 1.0 : 0.0)) + (r >= y ? 1.0 : 0.0);        // the neighbour (0 / 1 flags: one v_cndmask each, not two per 64-bit select)
     r = __builtin_fma(-q, y, ax);                                   // exact once q is the true quotient
     *ok = ax < y * 0x1p50 && r >= 0.0 && r < y && y >= 0x1p-900 && y <= 0x1p900;
     return copysign(r, x);
@@ -62,7 +62,9 @@ __host__ __device__ inline double rewind(double a, double period, double ref) {
 __host__ __device__ inline double rewind_try(double a, double period, double ref, double rperiod, bool* ok) {
     const double half = period / 2;
     const double r = fmod_pos_try((a - ref) + half, period, rperiod, ok);
-    const double mod = r == 0.0 ? 0.0 : (r < 0.0 ? r + period : r);   // jl_mod for y > 0
+    // jl_mod for y > 0: r + period for r < 0, +0 for r = +-0, r otherwise -- as one fma with a 0 / 1 flag (flag * period is exact,
+    // the sum is rounded once like the reference's r + period, and 0 * period + (-0) = +0)
+    const double mod = __builtin_fma(r < 0.0 ? 1.0 : 0.0, period, r);
     return (ref + mod) - half;
 }
 
