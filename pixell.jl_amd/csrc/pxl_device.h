@@ -67,6 +67,12 @@ __host__ __device__ inline double rewind_try(double a, double period, double ref
     const double mod = __builtin_fma(r < 0.0 ? 1.0 : 0.0, period, r);
     return (ref + mod) - half;
 }
+// ref = 0: `0 + mod` is mod itself (mod is never -0, see above), so the addition is dropped
+__host__ __device__ inline double rewind0_try(double a, double period, double rperiod, bool* ok) {
+    const double half = period / 2;
+    const double r = fmod_pos_try((a - 0.0) + half, period, rperiod, ok);
+    return __builtin_fma(r < 0.0 ? 1.0 : 0.0, period, r) - half;
+}
 
 // Pre-multiplied WCS scalars: the prologues of car_proj.jl:95-98 and :168-173.
 struct CarAffine {

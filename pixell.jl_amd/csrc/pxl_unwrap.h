@@ -186,8 +186,8 @@ struct UwSrcPix2 {          // m = rewind(pix2sky affine) - ref, ref = 0   (pix2
     __device__ inline void to_m(raw_t v, double* m) const {
         const double a = p2s_ra(c, v.x), d = p2s_dec(c, v.y);
         bool ok0, ok1;
-        m[0] = rewind_try(a, PXL_TWOPI_D, 0.0, rperiod, &ok0) - 0.0;
-        m[1] = rewind_try(d, PXL_TWOPI_D, 0.0, rperiod, &ok1) - 0.0;
+        m[0] = rewind0_try(a, PXL_TWOPI_D, rperiod, &ok0) - 0.0;
+        m[1] = rewind0_try(d, PXL_TWOPI_D, rperiod, &ok1) - 0.0;
         if (__builtin_expect(!(ok0 && ok1), 0)) {                   // NaN/Inf or a huge quotient: library fmod
             m[0] = rewind(a, PXL_TWOPI_D, 0.0, rperiod) - 0.0;
             m[1] = rewind(d, PXL_TWOPI_D, 0.0, rperiod) - 0.0;
@@ -223,10 +223,11 @@ struct UwSrcAng1 {          // the same on a plain vector
 };
 
 // wave-level data movement on the VALU (DPP / readlane) instead of ds_bpermute shuffles
-__device__ inline double uw_shr1(double v) {               // lane l gets lane l-1's value, lane 0 gets 0.0
+// lane l gets lane l-1's value, lane 0 gets `first` (wave_shr:1 leaves lane 0's destination -- the `old` operand -- alone)
+__device__ inline double uw_shr1_first(double v, double first) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);      // wave_shr:1
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(first), lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(first), hi, 0x138, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 __device__ inline double uw_lane63(double v) {
@@ -253,11 +254,12 @@ __device__ inline void uw_element(const SRC& s, int lane, int64_t k, bool valid,
     s.to_m(raw, m);
 #pragma unroll
     for (int r = 0; r < SRC::NROW; ++r) {
-        const double up = uw_shr1(m[r]);
-        mp[r] = lane == 0 ? mlast[r] : up;
-        const double d = (m[r] - mp[r]) * s.rperiod;
-        int g = (valid && k > 0 && d == d) ? (int)rint(d) : 0;     // |d| <= 1 for rewound values
-        c[r] = g < -1 ? -1 : (g > 1 ? 1 : g);                       // keep the 16-bit scan fields consistent whatever d was
+        mp[r] = uw_shr1_first(m[r], mlast[r]);
+        const double d = (m[r] - mp[r]) * s.rperiod;               // |d| <= 1 for rewound values
+        // clamped BEFORE the conversion (rint is monotone, so this is clamp(rint(d), -1, 1)): the 16-bit scan fields stay consistent
+        // whatever d was, and a NaN becomes -1 -- every element from the first NaN of a row on is written as NaN whatever its count
+        const int g = (int)rint(fmin(fmax(d, -1.0), 1.0));
+        c[r] = (valid && k > 0) ? g : 0;
     }
 }
 
@@ -389,14 +391,15 @@ __global__ __launch_bounds__(64) void k_unwind_apply(SRC src, typename SRC::raw_
                     const double yprev = mp[r] - (double)(rr - c[r]) * P;   // y[k-1] as the reference forms it
                     const double a = m[r] - yprev;
                     const double qa = a * rP;
-                    // rint(a / P) == r_k is certain when the approximate quotient is well inside (r-1/2, r+1/2);
-                    // otherwise (ties, mismatches) divide exactly like the reference
-                    if (!(fabs(qa - (double)rr) < 0.5 - (fabs(qa) + 1.0) * 1e-14)) {
+                    // rint(a / P) == r_k is certain when the approximate quotient is well inside (r-1/2, r+1/2): |r_k| < 2^31, so
+                    // qa is off by less than 2^31 * 4e-16 = 1e-6 and a fixed margin of 1e-4 is safe; otherwise (ties, mismatches:
+                    // two elements in ten thousand) divide exactly like the reference
+                    if (!(fabs(qa - (double)rr) < 0.4999)) {
                         const double q = a / P;
                         if (!(rint(q) == (double)rr)) bad = true;
                     }
                 }
-                y[r] = (k > 0 ? m[r] - (double)rr * P : m[r]) + ref;
+                y[r] = (m[r] - (double)(k > 0 ? rr : 0) * P) + ref;         // k = 0: m - 0 = m, bit for bit
             }
             if (WRITE && valid) SRC::store(out, k, y);
         }
@@ -492,8 +495,7 @@ __global__ __launch_bounds__(1024) void k_unwind_block(SRC src, typename SRC::ra
                 double y[2];
 #pragma unroll
                 for (int r = 0; r < NROW; ++r) {
-                    const double up = uw_shr1(m[u][r]);
-                    const double mp = lane == 0 ? mlast[r] : up;
+                    const double mp = uw_shr1_first(m[u][r], mlast[r]);
                     mlast[r] = uw_lane63(m[u][r]);
                     const int field = r == 0 ? (s & 0xffff) : (s >> 16);
                     const int rr = carry[r] + field - (lane + 1);
@@ -507,12 +509,12 @@ __global__ __launch_bounds__(1024) void k_unwind_block(SRC src, typename SRC::ra
                         const double yprev = mp - (double)(rr - cc[u][r]) * P;
                         const double a = m[u][r] - yprev;
                         const double qa = a * rP;
-                        if (!(fabs(qa - (double)rr) < 0.5 - (fabs(qa) + 1.0) * 1e-14)) {
+                        if (!(fabs(qa - (double)rr) < 0.4999)) {
                             const double q = a / P;
                             if (!(rint(q) == (double)rr)) bad = true;
                         }
                     }
-                    y[r] = (k > 0 ? m[u][r] - (double)rr * P : m[u][r]) + ref;
+                    y[r] = (m[u][r] - (double)(k > 0 ? rr : 0) * P) + ref;
                 }
                 if (pass == 1 && valid) SRC::store(out, k, y);
             }
