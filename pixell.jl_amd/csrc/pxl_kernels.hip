@@ -119,6 +119,7 @@ struct pxl_reproject_plan {
     int flags;
     int ns, pf;
     int ring_kb;       // LDS a wave's ring may take (KiB); the ring is halved until it fits
+    int min_tiles;     // the tile height is halved (down to 4 rows) while a launch has fewer tiles than this
     int nt;            // non-temporal stores (LDS-DMA kernel, full tiles)
     int64_t xchunk;
     double* zero_page;
@@ -649,6 +650,11 @@ int pxl_reproject_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[
         pl->pf = env_int("PXL_REPROJECT_PF", want_pf < 3 ? 3 : want_pf);
     }
     pl->ring_kb = env_int("PXL_REPROJECT_RING_KB", 17);
+    // 8192 tiles = 3.5 waves per resident slot.  The floor used to be 65 536 (round 1: "a few rounds of 16 waves per CU"), which cut
+    // the tiles of every launch below ~0.5 GB down to 4-8 rows -- each tile then pays its column setup for a handful of rows: a 1/4
+    // strip of the 2x refinement 0.547 -> 0.407 ms (53 -> 72 %), a 1/8 strip 0.295 -> 0.227 ms, the 1' same-resolution map 0.634 ->
+    // 0.620 ms, config 2 0.090 -> 0.082 ms; the IQU strips have more tiles than either floor (profiles/r03_tune_mintiles*.txt)
+    pl->min_tiles = env_int("PXL_REPROJECT_MIN_TILES", 8192);
     // non-temporal stores keep the column tables in the L2 (pxl_reproject_dma.h).  Measured (profiles/r03_tune_nt.txt): +0.5-0.7 % on
     // the 22 GB same-resolution IQU launch and +1.5 % when down-sampling 2x, but -1.7 % at 2x refinement and -2.4 ... -5 % on
     // launches of a few GB (a 1/8 strip, the 1' map), whose tables stay in the L2 anyway: -1 = by launch size at execute time
@@ -767,10 +773,10 @@ static int reproject_rows_impl(pxl_reproject_plan* pl, const void* src, void* ds
     p.seg = f32 ? pl->seg_dma32 : (use_dma ? pl->seg_dma : pl->seg);
     p.dxpos = pl->dxpos; p.dypos = pl->dypos; p.flags = pl->flags;
     p.ntx = (int32_t)((pl->nxo + TW - 1) / TW);
-    // tile height: the configured rh, halved while the launch would leave the chip short of waves
-    // (256 CUs x ~16 resident waves, a few rounds each); small maps and thin strips get shorter tiles
+    // tile height: the configured rh, halved while the launch would leave the chip short of waves (fewer than min_tiles tiles);
+    // small maps and thin strips get shorter tiles
     int rh = f32 ? pl->rh32 : pl->rh;
-    while (rh > 4 && (int64_t)p.ntx * ((nr + rh - 1) / rh) * pl->nc < 16 * 4096) rh >>= 1;
+    while (rh > 4 && (int64_t)p.ntx * ((nr + rh - 1) / rh) * pl->nc < pl->min_tiles) rh >>= 1;
     p.rh = rh;
     p.nty = (int32_t)((nr + rh - 1) / rh);
     p.ntiles = (int64_t)p.ntx * p.nty * pl->nc;

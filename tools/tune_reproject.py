@@ -20,7 +20,7 @@ import pixell_jl_amd as pj  # noqa: E402
 
 KEYS = {"rh": "PXL_REPROJECT_RH", "pairs": "PXL_REPROJECT_PAIRS", "flags": "PXL_REPROJECT_FLAGS",
         "variant": "PXL_REPROJECT_VARIANT", "pf": "PXL_REPROJECT_PF", "ns": "PXL_REPROJECT_NS",
-        "wg": "PXL_REPROJECT_WG", "ring": "PXL_REPROJECT_RING_KB", "order": "PXL_REPROJECT_ORDER", "nt": "PXL_REPROJECT_NT"}
+        "wg": "PXL_REPROJECT_WG", "ring": "PXL_REPROJECT_RING_KB", "mintiles": "PXL_REPROJECT_MIN_TILES", "order": "PXL_REPROJECT_ORDER", "nt": "PXL_REPROJECT_NT"}
 
 
 def main():

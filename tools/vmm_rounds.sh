@@ -1,10 +1,6 @@
 #!/bin/bash
-# scratch runner: Gnomonic evaluators before / after pxl_fastmath.h on one box, alternating processes
 set -o pipefail
-for rnd in 1 2 3; do
-  PXL_LIB_PATH=$PWD/tools/native/libpixell_hip_before_fastmath.so timeout -k 10 200 python tools/bench_tan_evaluators.py 2>/dev/null | sed 's/^{/{"build": "before (device libm)", /' >> gpurun_out/r03_fm_before_after.jsonl || exit 1
-  timeout -k 10 200 python tools/bench_tan_evaluators.py 2>/dev/null | sed 's/^{/{"build": "after (pxl_fastmath.h)", /' >> gpurun_out/r03_fm_before_after.jsonl || exit 1
-done
-PXL_LIB_PATH=$PWD/tools/native/libpixell_hip_before_fastmath.so timeout -k 10 200 python tools/bench_tan_mosaic.py 2>/dev/null | sed 's/^{/{"build": "before (device libm)", /' >> gpurun_out/r03_fm_before_after.jsonl
-timeout -k 10 200 python tools/bench_tan_mosaic.py 2>/dev/null | sed 's/^{/{"build": "after (pxl_fastmath.h)", /' >> gpurun_out/r03_fm_before_after.jsonl
-cat gpurun_out/r03_fm_before_after.jsonl | cut -c1-260
+timeout -k 10 300 python tools/tune_reproject.py --workload cfg3 --strip 3/8 --place --rounds 11 "mintiles=16384" "mintiles=8192" "mintiles=4096" "mintiles=2048" "mintiles=2048,rh=64" > gpurun_out/r03_tune_mintiles2_cfg3strip.txt 2>&1 || exit 1
+timeout -k 10 300 python tools/tune_reproject.py --workload cfg3 --strip 1/4 --place --rounds 11 "" "mintiles=8192" "mintiles=4096" "mintiles=2048" > gpurun_out/r03_tune_mintiles2_cfg3strip4.txt 2>&1 || exit 1
+timeout -k 10 300 python tools/tune_reproject.py --workload cfg3s --strip 3/8 --rounds 11 "" "mintiles=8192" "mintiles=4096" "mintiles=2048" > gpurun_out/r03_tune_mintiles2_cfg3sstrip.txt 2>&1 || exit 1
+for f in cfg3strip cfg3strip4 cfg3sstrip; do grep -A6 "^workload" gpurun_out/r03_tune_mintiles2_$f.txt; done
