@@ -627,7 +627,9 @@ int pxl_reproject_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[
     // tile height: 32 output rows when up-sampling in DEC, 16 when a tile consumes about as many source rows as it
     // writes (measured on five buffer placements of the 0.5-arcmin IQU map: 1.3-3.7 % faster than 32, 77.2 % at best;
     // the 2x refinement prefers 32 by 1.5 %)
-    pl->rh = env_int("PXL_REPROJECT_RH", sy >= 0.75 ? 16 : 32);
+    // Other scale factors (round 3, profiles/r03_tune_other3_*.txt): 4x refinement 8 rows (81.8 % against 75.2 % with 32; 16: 80.2 %),
+    // 2x coarsening 4 rows (75.4 % against 73.2 % with 16)
+    pl->rh = env_int("PXL_REPROJECT_RH", sy >= 1.5 ? 4 : (sy >= 0.75 ? 16 : (sy > 0.3 ? 32 : 8)));
     if (pl->rh < 1) pl->rh = 1;
     if (pl->rh > 64) pl->rh = 64;          // one lane per tile row holds the row-table entry
     pl->rh32 = env_int("PXL_REPROJECT_RH", 32);      // Float32 maps (4 pixels per lane) prefer 32 in both regimes
