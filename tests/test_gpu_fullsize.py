@@ -187,3 +187,86 @@ def test_config4_float32_storage_fullsize(pj, dev):
     for c in range(nc):                                  # plane by plane keeps the temporaries small
         assert torch.equal(dst32[c], dst64[c].float()), c
     plan.close()
+
+
+def test_config3_same_resolution_shift_fullsize(pj, O, dev):
+    """21600x10801 -> same shape, half-pixel-shifted WCS (second workload; bench `cfg3s`)."""
+    shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 21600)
+    nx, ny = shape_in
+    wcs_out = pj.CarClenshawCurtis(wcs_in.cdelt, (wcs_in.crpix[0] + 0.5, wcs_in.crpix[1] + 0.5), wcs_in.crval)
+    src = torch.empty((1, ny, nx), dtype=torch.float64, device=dev)
+    pj.fill_random_(src, 99)
+    plan = pj.ReprojectPlan((nx, ny, 1), wcs_in, (nx, ny), wcs_out, device=dev)
+    dst = torch.full(plan.dst_tensor_shape(), float("nan"), dtype=torch.float64, device=dev)
+    plan.execute(src, dst)
+    assert bool(torch.isfinite(dst).all())
+    _rows_vs_oracle(pj, O, src, dst, (nx, ny, 1), wcs_in, (nx, ny), wcs_out, [0, 1, 15, 16, 17, 5400, 10799, 10800])
+    left = torch.roll(src, 1, dims=2)
+    blk = 0.5 * (0.5 * left[:, 1:, :] + 0.5 * src[:, 1:, :]) + 0.5 * (0.5 * left[:, :-1, :] + 0.5 * src[:, :-1, :])
+    assert float((dst[:, 1:, :] - blk).abs().max()) < 1e-12
+    del left, blk
+    for variant in (2, 1):
+        plan.set_variant(variant)
+        other = torch.empty_like(dst)
+        plan.execute(src, other)
+        assert torch.equal(other, dst), variant
+        del other
+
+
+@pytest.mark.parametrize("workload", ["cfg3", "cfg3s"])
+def test_strips_of_config3_fullsize(pj, dev, workload):
+    """What a rank of a sharded config-3 job launches: the 1/8 and 1/4 declination strips (window plans, interior rows first,
+    boundary rows after the halo) of the full-size maps reproduce the unsharded launch bit for bit.  These launches are small
+    enough for the plan's tile-height floor to matter (short tiles below 8 192 tiles per launch)."""
+    shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 21600)
+    nx, ny = shape_in
+    if workload == "cfg3":
+        shape_out, wcs_out = pj.fullsky_geometry(2 * math.pi / 43200)
+    else:
+        shape_out, wcs_out = (nx, ny), pj.CarClenshawCurtis(wcs_in.cdelt, (wcs_in.crpix[0] + 0.5, wcs_in.crpix[1] + 0.5), wcs_in.crval)
+    full_src = torch.empty((1, ny, nx), dtype=torch.float64, device=dev)
+    pj.fill_random_(full_src, 4321)
+    full_plan = pj.ReprojectPlan((nx, ny, 1), wcs_in, shape_out, wcs_out, device=dev)
+    full_dst = torch.empty(full_plan.dst_tensor_shape(), dtype=torch.float64, device=dev)
+    full_plan.execute(full_src, full_dst)
+    for rank, world in ((0, 8), (3, 8), (7, 8), (1, 4), (2, 3)):
+        L = pj.sharding.DecStripLayout((nx, ny, 1), wcs_in, shape_out, wcs_out, rank, world)
+        plan = pj.ReprojectPlan((nx, ny, 1), wcs_in, shape_out, wcs_out, src_rows=L.src_window, dst_rows=L.dst_window, device=dev)
+        src = torch.full(L.src_tensor_shape(), float("nan"), dtype=torch.float64, device=dev)
+        src[:, L.own_slice(), :] = full_src[:, L.own[rank][0]:L.own[rank][1], :]
+        dst = torch.full(L.dst_tensor_shape(), float("nan"), dtype=torch.float64, device=dev)
+        plan.build_tables()
+        i_lo, i_hi = L.interior
+        plan.execute_rows(src, dst, i_lo, i_hi - i_lo)
+        for _, lo, hi in L.recvs:
+            src[:, lo - L.buf_lo:hi - L.buf_lo, :] = full_src[:, lo:hi, :]
+        if i_lo > 0:
+            plan.execute_rows(src, dst, 0, i_lo)
+        if i_hi < L.dst_window[1]:
+            plan.execute_rows(src, dst, i_hi, L.dst_window[1] - i_hi)
+        lo, n = L.dst_window
+        assert torch.equal(dst, full_dst[:, lo:lo + n, :]), (workload, rank, world)
+        del src, dst, plan
+
+
+@pytest.mark.parametrize("res_in,res_out", [(10800, 43200), (43200, 21600), (43200, 10800), (5400, 43200)])
+def test_other_scale_factors_fullsize(pj, O, dev, res_in, res_out):
+    """4x / 8x refinement and 2x / 4x coarsening onto or from the 0.5-arcmin grid: the plan picks other tile heights and prefetch
+    distances for them (`k_reproject_dma` bullets); sampled rows against the oracle, every kernel variant identical."""
+    shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / res_in)
+    shape_out, wcs_out = pj.fullsky_geometry(2 * math.pi / res_out)
+    nx, ny = shape_in
+    src = torch.empty((1, ny, nx), dtype=torch.float64, device=dev)
+    pj.fill_random_(src, res_in + res_out)
+    plan = pj.ReprojectPlan((nx, ny, 1), wcs_in, shape_out, wcs_out, device=dev)
+    dst = torch.full(plan.dst_tensor_shape(), float("nan"), dtype=torch.float64, device=dev)
+    plan.execute(src, dst)
+    assert bool(torch.isfinite(dst).all())
+    nyo = shape_out[1]
+    _rows_vs_oracle(pj, O, src, dst, (nx, ny, 1), wcs_in, shape_out, wcs_out, [0, 1, 3, 4, 7, 8, 9, nyo // 2, nyo - 2, nyo - 1])
+    for variant in (2, 1):
+        plan.set_variant(variant)
+        other = torch.empty_like(dst)
+        plan.execute(src, other)
+        assert torch.equal(other, dst), variant
+        del other
