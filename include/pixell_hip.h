@@ -268,8 +268,34 @@ int pxl_fits_swap_f32(const void* src, void* dst, int64_t n, void* stream);
  *      window b, each writing window_bytes / 4 bytes of ZEROS (both windows are overwritten).  `us` receives the median of
  *      `reps` launches in microseconds; with 1 GiB windows about 380 us = same class, 305 us = different classes.  It
  *      synchronises `stream`.  A host can map an allocation with it and put a destination across a class boundary
- *      (pixell.jl_amd/placement.py); nothing in the library calls it.  No reference counterpart.                        */
+ *      (pixell.jl_amd/placement.py does; pxl_mem_pair_alloc below is the same rule natively).                            */
 int pxl_mem_probe_pair(void* a, void* b, size_t window_bytes, int reps, float* us, void* stream);
+
+/* A (source, destination) pair of maps placed by that rule: ONE hipMalloc of src + dst + headroom bytes (capped at the free
+ * memory less 6 GiB), its classes mapped with the probe (one 1 GiB window every 2 GiB), the destination centred on the
+ * boundary between two classes that has the most room on both sides, the source in a stretch of a class the destination does
+ * not touch -- looked for in separate allocations (up to 96 GiB of candidates, freed again) when the allocation holds none.
+ * Without a boundary inside the allocation the layout is the plain one (source first, destination at the top).  The source is
+ * zero-filled; both pointers are 2 MiB aligned.  Topology discovery only: nothing about the caller's kernel is timed.  The
+ * head-room stays allocated until pxl_mem_pair_free (hipMalloc cannot return part of an allocation): 144 GiB is what it takes
+ * for all three classes to show up on a fresh device.  Uses the current device; synchronises `stream`.                    */
+typedef struct pxl_mem_pair {
+    void* src;                 /* src_bytes, zero-filled */
+    void* dst;                 /* dst_bytes */
+    void* arena;               /* the allocation dst (and normally src) lives in */
+    void* src_alloc;           /* the separate allocation holding src, or NULL */
+    uint64_t arena_bytes;
+    uint64_t src_offset;       /* of src within arena (0 when src_alloc is set) */
+    uint64_t dst_offset;
+    int32_t classes;           /* memory classes seen inside the allocation: 1..3 */
+    int32_t dst_two_classes;   /* 1: dst straddles a class boundary */
+    int32_t src_own_class;     /* 1: src lies in a class dst does not touch */
+    int32_t probes;            /* probe launches spent (0.3 ms each) */
+    int32_t separate_tried;    /* separate source allocations tried */
+    int32_t reserved_;
+} pxl_mem_pair;
+int pxl_mem_pair_alloc(uint64_t src_bytes, uint64_t dst_bytes, uint64_t headroom_bytes, pxl_mem_pair* out, void* stream);
+int pxl_mem_pair_free(pxl_mem_pair* pair);
 
 /* ---- synthetic inputs (benchmark plumbing, deterministic counter-based generator):
  *      fill n doubles with N(0,1) (kind 0) or U[0,1) (kind 1) from splitmix64(seed, index+offset);

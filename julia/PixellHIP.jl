@@ -429,6 +429,33 @@ function mem_probe_pair(a::Ptr, b::Ptr; window::Integer=1 << 30, reps::Integer=3
     return us[]
 end
 
+# The same rule natively (pxl_mem_pair_alloc): one ccall, tested from the Python side on the device (tests/test_gpu_placement.py)
+mutable struct MemPair                 # == struct pxl_mem_pair
+    src::Ptr{Cvoid}
+    dst::Ptr{Cvoid}
+    arena::Ptr{Cvoid}
+    src_alloc::Ptr{Cvoid}
+    arena_bytes::UInt64
+    src_offset::UInt64
+    dst_offset::UInt64
+    classes::Int32
+    dst_two_classes::Int32
+    src_own_class::Int32
+    probes::Int32
+    separate_tried::Int32
+    reserved_::Int32
+    MemPair() = new(C_NULL, C_NULL, C_NULL, C_NULL, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+end
+# (src, dst, pair): device arrays over the library's allocation; `pair` owns the memory (freed by its finalizer, which the two
+# arrays keep from running by holding a reference to it)
+function place_pair_native(::Type{T}, src_dims::NTuple{N,Int}, dst_dims::NTuple{M,Int}; headroom::Integer=144 << 30) where {T,N,M}
+    pair = MemPair()
+    check(ccall((:pxl_mem_pair_alloc, libpixell_hip), Cint, (UInt64, UInt64, UInt64, Ptr{Cvoid}, Ptr{Cvoid}),
+                prod(src_dims) * sizeof(T), prod(dst_dims) * sizeof(T), headroom, pointer_from_objref(pair), NULLSTREAM))
+    finalizer(p -> ccall((:pxl_mem_pair_free, libpixell_hip), Cint, (Ptr{Cvoid},), pointer_from_objref(p)), pair)
+    return HIPArray{T,N}(Ptr{T}(pair.src), src_dims, pair), HIPArray{T,M}(Ptr{T}(pair.dst), dst_dims, pair), pair
+end
+
 # class label of every `step`-spaced 1 GiB window of `arena` (labels 1, 2, 3 in order of appearance)
 function map_classes(arena::HIPArray{UInt8,1}; step::Integer=2 << 30, window::Integer=1 << 30)
     thr = 2.0 * window / 6.25e6                       # microseconds: above = the two windows share a class (~383 vs ~305 us per GiB)
@@ -476,7 +503,7 @@ function place_pair(::Type{T}, src_dims::NTuple{N,Int}, dst_dims::NTuple{M,Int};
     return src, dst
 end
 
-export mem_probe_pair, map_classes, place_pair
+export mem_probe_pair, map_classes, place_pair, place_pair_native, MemPair
 export HIPArray, posmap_device, reproject, reproject_generic, reproject!, ReprojectPlan, sample_bilinear, SamplePairs, HaloXfer, sharded_step!
 export PxlComm, comm_unique_id, comm_init_rank, comm_destroy, comm_backend
 end # module

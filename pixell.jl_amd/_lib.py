@@ -78,9 +78,19 @@ SIGNATURES = {
     "pxl_fits_encode_f64": (C.c_int, [_P, _P, _I64, _P]),
     "pxl_fits_swap_f32": (C.c_int, [_P, _P, _I64, _P]),
     "pxl_mem_probe_pair": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_float), _P]),
+    "pxl_mem_pair_alloc": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, _P, _P]),
+    "pxl_mem_pair_free": (C.c_int, [_P]),
     "pxl_fill_random_f64": (C.c_int, [_P, _I64, C.c_uint64, C.c_uint64, C.c_int, _P]),
     "pxl_fill_sphere_points_f64": (C.c_int, [_P, _I64, C.c_uint64, C.c_uint64, _P]),
 }
+
+class MemPair(C.Structure):
+    """struct pxl_mem_pair (include/pixell_hip.h)."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("arena", C.c_void_p), ("src_alloc", C.c_void_p),
+                ("arena_bytes", C.c_uint64), ("src_offset", C.c_uint64), ("dst_offset", C.c_uint64),
+                ("classes", C.c_int32), ("dst_two_classes", C.c_int32), ("src_own_class", C.c_int32), ("probes", C.c_int32),
+                ("separate_tried", C.c_int32), ("reserved_", C.c_int32)]
+
 
 _lib = None
 

@@ -319,6 +319,8 @@ int pxl_mem_probe_pair(void* a, void* b, size_t window_bytes, int reps, float* u
     return PXL_OK;
 }
 
+#include "pxl_place.h"
+
 int pxl_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

@@ -323,3 +323,46 @@ def place_pair_compact(src_shape, dst_shape, dtype=torch.float64, device="cuda",
     dst = dst.view(tuple(dst_shape))
     src.zero_()
     return src, dst, {"placement": note, "source": src_note, "candidates_minor_share": tried, "allocation_GiB": round((ns + nd) * esz / GiB, 1)}
+
+
+class _NativePair:
+    """Owns a struct pxl_mem_pair; device memory is handed to torch through __cuda_array_interface__ views that keep this alive."""
+
+    def __init__(self, pair):
+        self.pair = pair
+
+    def view(self, ptr, shape, dtype):
+        typestr = {torch.float64: "<f8", torch.float32: "<f4", torch.uint8: "|u1"}[dtype]
+        owner = self
+
+        class _View:
+            __cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+            keep = owner
+        return torch.as_tensor(_View(), device="cuda")
+
+    def __del__(self):
+        try:
+            _lib.load().pxl_mem_pair_free(C.byref(self.pair))
+        except Exception:           # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+def place_pair_native(src_shape, dst_shape, dtype=torch.float64, device="cuda", headroom_gib=144):
+    """The same placement through the C ABI (pxl_mem_pair_alloc: what a Julia or C host calls): (src, dst, info).  The library owns
+    the allocation; it is freed when the last of the two tensors (and `info["owner"]`) is gone."""
+    import math
+    dev = torch.device(device)
+    esz = torch.empty((), dtype=dtype).element_size()
+    pair = _lib.MemPair()
+    with torch.cuda.device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(_lib.load().pxl_mem_pair_alloc(math.prod(src_shape) * esz, math.prod(dst_shape) * esz, int(headroom_gib * GiB),
+                                                  C.byref(pair), stream))
+        owner = _NativePair(pair)
+        src = owner.view(pair.src, src_shape, dtype)
+        dst = owner.view(pair.dst, dst_shape, dtype)
+    info = {"owner": owner, "allocation_GiB": round(pair.arena_bytes / GiB, 1), "src_offset_GiB": round(pair.src_offset / GiB, 2),
+            "dst_offset_GiB": round(pair.dst_offset / GiB, 2), "classes": pair.classes, "dst_two_classes": bool(pair.dst_two_classes),
+            "src_own_class": bool(pair.src_own_class), "probes": pair.probes, "separate_source_allocation": bool(pair.src_alloc),
+            "separate_tried": pair.separate_tried}
+    return src, dst, info

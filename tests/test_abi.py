@@ -56,9 +56,9 @@ def _c_prototypes():
 # what each Julia ccall type may stand for on the C side (opaque handles travel as Ptr{Cvoid})
 _JULIA_TO_C = {
     "Ref{CarWCS}": {"pxl_car_wcs*"},
-    "Int64": {"int64_t"}, "Cint": {"int"}, "Cdouble": {"double"}, "Csize_t": {"size_t"},
+    "Int64": {"int64_t"}, "UInt64": {"uint64_t"}, "Cint": {"int"}, "Cdouble": {"double"}, "Csize_t": {"size_t"},
     "Ptr{Cdouble}": {"double*"}, "Ptr{Cfloat}": {"float*"}, "Ptr{Int64}": {"int64_t*"},
-    "Ptr{Cvoid}": {"void*", "pxl_reproject_plan*"},
+    "Ptr{Cvoid}": {"void*", "pxl_reproject_plan*", "pxl_mem_pair*"},
     "Ptr{Ptr{Cvoid}}": {"void**", "pxl_reproject_plan**"},
     "Ptr{UInt8}": {"char*", "void*"},
     "Ptr{HaloXfer}": {"pxl_halo_xfer*"},
@@ -135,6 +135,22 @@ def test_version_and_error_channel_without_gpu(pj):
     rc = lib.pxl_pix2sky_car_f64(None, 0, None, None, 0, None)
     assert rc == -22
     assert "WCS" in pj._lib.last_error()
+
+
+def test_mem_pair_struct_mirrors(pj):
+    """struct pxl_mem_pair: the header, the ctypes mirror and the Julia mirror list the same fields with the same types."""
+    header = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    body = re.search(r"typedef struct pxl_mem_pair \{(.*?)\}", header, flags=re.S).group(1)
+    cfields = [(t.replace(" ", ""), n) for t, n in re.findall(r"([\w \*]+?)\s*\b(\w+);", body)]
+    assert [n for _, n in cfields] == [n for n, _ in pj._lib.MemPair._fields_]
+    cmap = {"void*": ctypes.c_void_p, "uint64_t": ctypes.c_uint64, "int32_t": ctypes.c_int32}
+    assert [cmap[t] for t, _ in cfields] == [t for _, t in pj._lib.MemPair._fields_]
+    text = open(os.path.join(ROOT, "julia", "PixellHIP.jl")).read()
+    jbody = re.search(r"mutable struct MemPair[^\n]*\n(.*?)\n    MemPair\(\)", text, flags=re.S).group(1)
+    jfields = re.findall(r"^\s*(\w+)::([\w{}]+)", jbody, flags=re.M)
+    jmap = {"void*": "Ptr{Cvoid}", "uint64_t": "UInt64", "int32_t": "Int32"}
+    assert jfields == [(n, jmap[t]) for t, n in cfields]
+    assert ctypes.sizeof(pj._lib.MemPair) == 4 * 8 + 3 * 8 + 6 * 4
 
 
 def test_struct_layout_matches_reference_wcs(pj):

@@ -116,3 +116,43 @@ def test_separate_allocation_in_another_class(pj, dev):
         found.fill_(1.0)
     else:
         assert grown <= (64 << 20)
+
+
+def test_native_pair_alloc_through_the_abi(pj, dev):
+    """pxl_mem_pair_alloc / pxl_mem_pair_free (what a Julia or C host calls): the pair is usable, disjoint, inside the allocation
+    it reports, the source zero-filled; a reprojection into it equals the one into plain tensors bit for bit; freeing returns the
+    memory; bad arguments are refused."""
+    import ctypes as C
+    import math
+    lib = pj.load_library()
+    shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 10800)
+    shape_out, wcs_out = pj.fullsky_geometry(2 * math.pi / 21600)
+    nx, ny = shape_in
+    free0, _ = torch.cuda.mem_get_info(dev)
+    src, dst, info = pj.place_pair_native((1, ny, nx), (1, shape_out[1], shape_out[0]), device=dev, headroom_gib=40)
+    p = info["owner"].pair
+    bs, bd = src.numel() * 8, dst.numel() * 8
+    assert 1 <= info["classes"] <= 3 and info["probes"] >= 1
+    assert p.dst >= p.arena and p.dst + bd <= p.arena + p.arena_bytes and p.dst % (2 << 20) == 0 and p.src % (2 << 20) == 0
+    if not p.src_alloc:
+        assert p.src >= p.arena and p.src + bs <= p.arena + p.arena_bytes
+        assert p.src + bs <= p.dst or p.dst + bd <= p.src
+    assert src.data_ptr() == p.src and dst.data_ptr() == p.dst
+    assert float(src.abs().max()) == 0.0
+    pj.fill_random_(src, 5)
+    plan = pj.ReprojectPlan((nx, ny, 1), wcs_in, shape_out, wcs_out, device=dev)
+    plan.execute(src, dst)
+    ref = torch.empty(plan.dst_tensor_shape(), dtype=torch.float64, device=dev)
+    plan.execute(src.clone(), ref)
+    assert torch.equal(dst, ref)
+    del src, dst, ref, plan, p
+    info.clear()
+    torch.cuda.empty_cache()
+    import gc
+    gc.collect()
+    free1, _ = torch.cuda.mem_get_info(dev)
+    assert free1 >= free0 - (1 << 30)                                   # the allocation went back to the driver
+    bad = pj._lib.MemPair()
+    assert lib.pxl_mem_pair_alloc(0, 1 << 20, 0, C.byref(bad), None) != 0
+    assert lib.pxl_mem_pair_alloc(1 << 20, 1 << 20, 0, None, None) != 0
+    assert lib.pxl_mem_pair_free(None) != 0

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--placements", type=int, default=1, help="re-allocate the maps this many times (physical placement moves the kernel by up to 10 %%) and print every variant per placement")
     ap.add_argument("--place", action="store_true", help="maps from pj.place_pair (destination across a boundary between two memory classes) instead of torch.empty")
+    ap.add_argument("--place-native", action="store_true", help="maps from the C ABI's pxl_mem_pair_alloc (pj.place_pair_native)")
     ap.add_argument("--place-compact", action="store_true", help="maps from pj.place_pair_compact (two-class destination without head-room)")
     ap.add_argument("--strip", default=None, help="R/W: time the declination strip of rank R of W (interior rows only)")
     ap.add_argument("variants", nargs="+")
@@ -56,6 +57,13 @@ def main():
         t0 = time.perf_counter()
         src, dst, info = pj.place_pair_compact((nc, ny_s, nx), (nc, nyo_s, nxo), dtype=torch.float64, device=dev)
         print("place_pair_compact: %.2f s" % (time.perf_counter() - t0), info, "allocated now: %.1f GiB" % (torch.cuda.memory_reserved(dev) / 2**30))
+        pj.fill_random_(src, 1234)
+    elif args.place_native:
+        import time
+        t0 = time.perf_counter()
+        src, dst, info = pj.place_pair_native((nc, ny_s, nx), (nc, nyo_s, nxo), dtype=torch.float64, device=dev)
+        arena_keep = info.pop("owner")
+        print("place_pair_native: %.2f s" % (time.perf_counter() - t0), info)
         pj.fill_random_(src, 1234)
     elif args.place:
         import time

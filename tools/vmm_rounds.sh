@@ -1,10 +1,8 @@
 #!/bin/bash
-# scratch runner: previous build against the current one, alternating processes on one box
 set -o pipefail
-for rnd in 1 2 3; do
-  for wl in cfg4 cfg3; do
-    PXL_LIB_PATH=$PWD/tools/native/libpixell_hip_prev.so timeout -k 10 200 python tools/tune_reproject.py --workload $wl --place --rounds 9 "" 2>/dev/null | grep median | sed "s/^/prev $wl /" >> gpurun_out/r03_ab_waittree.txt || exit 1
-    timeout -k 10 200 python tools/tune_reproject.py --workload $wl --place --rounds 9 "" 2>/dev/null | grep median | sed "s/^/new  $wl /" >> gpurun_out/r03_ab_waittree.txt || exit 1
-  done
-done
-cat gpurun_out/r03_ab_waittree.txt
+timeout -k 10 300 python -m pytest tests/test_gpu_placement.py -x -q -m gpu 2>&1 | tail -3
+timeout -k 10 300 python tools/tune_reproject.py --workload cfg3 --place-native --rounds 9 "" 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r03_place_native.txt
+timeout -k 10 300 python tools/tune_reproject.py --workload cfg3 --place --rounds 9 "" 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r03_place_native.txt
+timeout -k 10 300 python tools/tune_reproject.py --workload cfg3 --rounds 9 "" 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r03_place_native.txt
+timeout -k 10 300 python tools/tune_reproject.py --workload cfg4 --place-native --rounds 7 "" 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r03_place_native.txt
+timeout -k 10 300 python tools/tune_reproject.py --workload cfg4 --rounds 7 "" 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r03_place_native.txt
