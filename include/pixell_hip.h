@@ -287,7 +287,8 @@ typedef struct pxl_mem_pair {
     uint64_t arena_bytes;
     uint64_t src_offset;       /* of src within arena (0 when src_alloc is set) */
     uint64_t dst_offset;
-    int32_t classes;           /* memory classes seen inside the allocation: 1..3 */
+    int32_t classes;           /* labels given to the allocation's windows: the part has 3 classes; a window that straddles a
+                                  boundary can get a label of its own */
     int32_t dst_two_classes;   /* 1: dst straddles a class boundary */
     int32_t src_own_class;     /* 1: src lies in a class dst does not touch */
     int32_t probes;            /* probe launches spent (0.3 ms each) */

@@ -83,11 +83,12 @@ def test_native_cpp_host(tmp_path):
            "-Wl,-rpath," + libdir, "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    for args in (["2048", "2", "same", "3"], ["1024", "1", "refine", "3"]):
+    for args in (["2048", "2", "same", "3"], ["1024", "1", "refine", "3"], ["8192", "1", "refine", "3", "placed", "24"]):
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (r.stdout, r.stderr)
         d = json.loads(r.stdout.strip().splitlines()[-1])
         assert d["native"] and d["kernel_ms"] > 0 and d["unity_err"] < 1e-13
+        assert d["placed"] == (len(args) > 4) and (not d["placed"] or d["classes"] >= 1)
 
 
 def test_native_host_makes_its_own_communicator(tmp_path):

@@ -4,7 +4,7 @@
 // interpreter in the way, and as the smallest example of a host that is not the Python mirror.
 //
 //   hipcc --offload-arch=gfx950 -O2 -I include tools/native/native_bench.cpp -L pixell.jl_amd -lpixell_hip \
-//         -Wl,-rpath,$PWD/pixell.jl_amd -o native_bench && ./native_bench 43200 3 same 20
+//         -Wl,-rpath,$PWD/pixell.jl_amd -o native_bench && ./native_bench 43200 3 same 20 [placed [headroom GiB]]
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -38,6 +38,9 @@ int main(int argc, char** argv) {
     int64_t nc = argc > 2 ? atoll(argv[2]) : 1;
     bool refine = argc > 3 && strcmp(argv[3], "refine") == 0;     // "same": half-pixel shift; "refine": 2x grid
     int steps = argc > 4 ? atoi(argv[4]) : 10;
+    // "placed GiB": the maps from pxl_mem_pair_alloc with that much head-room (class-aware placement through the C ABI)
+    const bool placed = argc > 5 && strcmp(argv[5], "placed") == 0;
+    const uint64_t headroom = (uint64_t)(argc > 6 ? atoll(argv[6]) : 144) << 30;
 
     int64_t shape_in[3], shape_out[2];
     pxl_car_wcs win, wout;
@@ -48,10 +51,17 @@ int main(int argc, char** argv) {
 
     const size_t n_src = (size_t)shape_in[0] * shape_in[1] * nc, n_dst = (size_t)shape_out[0] * shape_out[1] * nc;
     double *src = nullptr, *dst = nullptr;
-    CHECK_HIP(hipMalloc(&src, n_src * 8));
-    CHECK_HIP(hipMalloc(&dst, n_dst * 8));
     hipStream_t st;
     CHECK_HIP(hipStreamCreate(&st));
+    pxl_mem_pair pair;
+    memset(&pair, 0, sizeof pair);
+    if (placed) {
+        CHECK_PXL(pxl_mem_pair_alloc(n_src * 8, n_dst * 8, headroom, &pair, st));
+        src = (double*)pair.src; dst = (double*)pair.dst;
+    } else {
+        CHECK_HIP(hipMalloc(&src, n_src * 8));
+        CHECK_HIP(hipMalloc(&dst, n_dst * 8));
+    }
 
     pxl_reproject_plan* plan = nullptr;
     CHECK_PXL(pxl_reproject_plan_create(&win, shape_in, 0, shape_in[1], &wout, shape_out, 0, shape_out[1], &plan));
@@ -84,11 +94,13 @@ int main(int argc, char** argv) {
     ms /= (float)steps;
     double bytes = 8.0 * (double)(n_src + n_dst);
     printf("{\"native\": true, \"shape_in\": [%lld, %lld, %lld], \"shape_out\": [%lld, %lld], \"kernel_ms\": %.4f, "
-           "\"algorithmic_GBps\": %.1f, \"frac_of_8TBps\": %.4f, \"Mpix_per_s\": %.1f, \"unity_err\": %.3g}\n",
+           "\"algorithmic_GBps\": %.1f, \"frac_of_8TBps\": %.4f, \"Mpix_per_s\": %.1f, \"unity_err\": %.3g, \"placed\": %s, "
+           "\"classes\": %d, \"dst_two_classes\": %d, \"src_own_class\": %d, \"allocation_GiB\": %.1f}\n",
            (long long)shape_in[0], (long long)shape_in[1], (long long)nc, (long long)shape_out[0], (long long)shape_out[1],
-           ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0, (double)n_dst / ms / 1e3, worst);
+           ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0, (double)n_dst / ms / 1e3, worst, placed ? "true" : "false",
+           pair.classes, pair.dst_two_classes, pair.src_own_class, pair.arena_bytes / 1073741824.0);
     pxl_reproject_plan_destroy(plan);
-    (void)hipFree(src);
-    (void)hipFree(dst);
+    if (placed) CHECK_PXL(pxl_mem_pair_free(&pair));
+    else { (void)hipFree(src); (void)hipFree(dst); }
     return 0;
 }

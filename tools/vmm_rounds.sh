@@ -1,8 +1,10 @@
 #!/bin/bash
 set -o pipefail
-timeout -k 10 300 python -m pytest tests/test_gpu_placement.py -x -q -m gpu 2>&1 | tail -3
-timeout -k 10 300 python tools/tune_reproject.py --workload cfg3 --place-native --rounds 9 "" 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r03_place_native.txt
-timeout -k 10 300 python tools/tune_reproject.py --workload cfg3 --place --rounds 9 "" 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r03_place_native.txt
-timeout -k 10 300 python tools/tune_reproject.py --workload cfg3 --rounds 9 "" 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r03_place_native.txt
-timeout -k 10 300 python tools/tune_reproject.py --workload cfg4 --place-native --rounds 7 "" 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r03_place_native.txt
-timeout -k 10 300 python tools/tune_reproject.py --workload cfg4 --rounds 7 "" 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r03_place_native.txt
+timeout -k 10 400 python -m pytest tests/test_gpu_entrypoints.py -x -q -m gpu -k native 2>&1 | tail -3
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -I include tools/native/native_bench.cpp -L pixell.jl_amd -lpixell_hip -Wl,-rpath,$PWD/pixell.jl_amd -o /tmp/native_bench || exit 1
+for rnd in 1 2; do
+  /tmp/native_bench 21600 1 refine 20 | tee -a gpurun_out/r03_native_host_placed.jsonl
+  /tmp/native_bench 21600 1 refine 20 placed | tee -a gpurun_out/r03_native_host_placed.jsonl
+  /tmp/native_bench 43200 3 same 10 | tee -a gpurun_out/r03_native_host_placed.jsonl
+  /tmp/native_bench 43200 3 same 10 placed | tee -a gpurun_out/r03_native_host_placed.jsonl
+done
