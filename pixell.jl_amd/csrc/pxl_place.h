@@ -56,7 +56,7 @@ static int map_classes(char* base, uint64_t nbytes, uint64_t step, hipStream_t s
 static double foreign_share(const ClassMap& cm, uint64_t o, uint64_t n, unsigned used) {
     int tot = 0, fr = 0;
     for (size_t k = 0; k < cm.offs.size(); ++k)
-        if (cm.offs[k] + GiB > o && cm.offs[k] < o + n) { ++tot; if (!((used >> cm.labels[k]) & 1u)) ++fr; }
+        if (cm.offs[k] + GiB > o && cm.offs[k] < o + n) { ++tot; if (!((used >> (cm.labels[k] & 31)) & 1u)) ++fr; }
     return tot ? (double)fr / tot : 1.0;
 }
 
@@ -104,7 +104,7 @@ int pxl_mem_pair_alloc(uint64_t src_bytes, uint64_t dst_bytes, uint64_t headroom
         two = 1;
         unsigned used = 0;
         for (size_t k = 0; k < cm.offs.size(); ++k)
-            if (cm.offs[k] + GiB > dst_off && cm.offs[k] < dst_off + bd) used |= 1u << cm.labels[k];
+            if (cm.offs[k] + GiB > dst_off && cm.offs[k] < dst_off + bd) used |= 1u << (cm.labels[k] & 31);
         // the source: the free stretch with the largest share of windows in a class the destination does not touch, far from it
         double best_share = -1.0; uint64_t best_dist = 0; bool have = false;
         auto consider = [&](uint64_t o) {
@@ -128,7 +128,7 @@ int pxl_mem_pair_alloc(uint64_t src_bytes, uint64_t dst_bytes, uint64_t headroom
         {
             unsigned seen = 0;
             for (size_t k = 0; k < cm.offs.size(); ++k)
-                if (cm.offs[k] + GiB > dst_off && cm.offs[k] < dst_off + bd && !((seen >> cm.labels[k]) & 1u)) { seen |= 1u << cm.labels[k]; refs.push_back(arena + cm.offs[k]); }
+                if (cm.offs[k] + GiB > dst_off && cm.offs[k] < dst_off + bd && !((seen >> (cm.labels[k] & 31)) & 1u)) { seen |= 1u << (cm.labels[k] & 31); refs.push_back(arena + cm.offs[k]); }
         }
         const float thr = (float)(2.0 * GiB / 6.25e6);
         std::vector<char*> ballast;
