@@ -1,17 +1,19 @@
-// pxl_fastmath.h -- atan2, asin and rsqrt for the Gnomonic evaluators; included by pxl_kernels.hip and, on the host, by
+// pxl_fastmath.h -- atan2, asin, sincos and rsqrt for the Gnomonic evaluators; included by pxl_kernels.hip and, on the host, by
 // tests/native/fastmath_check.cpp (which measures them against long double libm: tests/test_fastmath.py).
 //
 // Why not the device libm: the Gnomonic evaluators are bound by FP64 instruction issue, and ocml's atan2 / asin / sincos cost
 // well over a hundred wave instructions each (rational kernels with a second division, IEEE divisions and square roots with their
-// scaling steps, selects of 64-bit constants).  sincos stays with the library: a Cody-Waite version written here (three-part pi/2,
-// tail carried into both kernels, 0.78 ulp) measured 9 % slower than ocml's on the device, and a no-reduction fast path for
-// |x| <= pi/4 does not apply to wide patches.
+// scaling steps, selects of 64-bit constants), its sincos ~65 (double-double reduction, quadrant selects).
 // The paths that use these functions are tolerance-checked against the oracle (glibc) anyway -- the reference's own bar for its
 // Gnomonic code is an L1 bound against wcslib (test_geometry.jl:116-119) -- so what is needed is a couple of ulp, cheaply:
 //   pxl_fm_atan2   one division (reciprocal seed + two Newton steps), an 11-term polynomial on |t| <= tan(pi/8), two further reduction centres (1/2 and 1) chosen so
 //                  that the reduced angle is at most 0.28 of the result (its error is not amplified); <= 2 ulp measured
 //   pxl_fm_asin    one 13-term polynomial for both halves (|v| <= 1/2 directly, else pi/2 - 2 asin(sqrt((1 - |v|)/2)) with the
 //                  square root's residual carried along); <= 2 ulp measured
+//   pxl_fm_sincos  Cody-Waite reduction by pi/2 in two 53-bit parts (first step exact, second rounded once), 7- and 6-term
+//                  kernels, quadrant step = one swap and two sign flips; <= 1.5 ulp for |x| <= 2^19 pi/2, refused beyond (the
+//                  caller then uses the library).  A first version that carried the reduction's tail into both kernels and chose
+//                  with 64-bit selects was 9 % SLOWER than the library's; this one is 16 % faster (sky2pix 57 -> 66 %)
 //   pxl_fm_rsqrt   seed + one third-order step; <= 1 ulp
 // Every product-sum is an explicit fma (the translation unit is compiled with -ffp-contract=off).  Coefficients:
 // tools/gen_fastmath_coeffs.py (Chebyshev fits at 60 digits).
@@ -153,4 +155,39 @@ PXL_FM_HD double pxl_fm_asin(double v) {
     const double rbig = u + (uerr - (((blo + p) + (blo + p)) - PXL_FM_PIO2_2));
     const double rsmall = av + p;
     return __builtin_copysign(big ? rbig : rsmall, v);
+}
+
+// v with the sign flipped when `neg` is nonzero in bit 1 (neg = q & 2, or (q + 1) & 2): one shift and one xor on the high word
+PXL_FM_HD double pxl_fm_flip_if_bit1(double v, int q) {
+    unsigned long long b;
+    __builtin_memcpy(&b, &v, 8);
+    b ^= (unsigned long long)((unsigned)q & 2u) << 62;
+    __builtin_memcpy(&v, &b, 8);
+    return v;
+}
+
+// sin and cos of x for |x| <= 2^19 pi/2 (returns true); false, nothing written, beyond that and for NaN / Inf: the caller uses
+// the library.  Cody-Waite reduction by pi/2 in two 53-bit parts -- the first step is exact (|n| < 2^20: the difference is a
+// multiple of 2^-53 below 1 in magnitude), the second is rounded once, which is the whole reduction error: 0.5 ulp of the reduced
+// argument (the third part of pi/2, n * 1e-33, is dropped) -- then the two kernels on |r| <= pi/4 and a quadrant step made of one
+// swap and two sign flips.  <= 1.5 ulp; about 40 instructions against the library's ~65 (half of those are its reduction's
+// double-double arithmetic and the selects of the quadrant logic).
+PXL_FM_HD bool pxl_fm_sincos(double x, double* sn, double* cs) {
+    constexpr double S[PXL_FM_SIN_S_N] = PXL_FM_SIN_S;
+    constexpr double Cc[PXL_FM_COS_C_N] = PXL_FM_COS_C;
+    if (!(__builtin_fabs(x) <= 823549.0)) return false;
+    const double n = __builtin_rint(x * PXL_FM_2OPI);
+    const double r = pxl_fm_kfma(-n, PXL_FM_PIO2_2, pxl_fm_kfma(-n, PXL_FM_PIO2_1, x));
+    const double z = r * r;
+    const double sv = __builtin_fma(r * z, pxl_fm_horner(S, z), r);         // r + r z S(z)
+    // 1 - z/2 + z^2 C(z), the leading difference with its rounding error
+    const double hz = 0.5 * z;
+    const double one_m = 1.0 - hz;
+    const double cv = one_m + (((1.0 - one_m) - hz) + (z * z) * pxl_fm_horner(Cc, z));
+    // quadrant q = n mod 4: (sin, cos) = (s, c), (c, -s), (-s, -c), (-c, s)
+    const int q = (int)n;
+    const bool odd = q & 1;
+    *sn = pxl_fm_flip_if_bit1(odd ? cv : sv, q);
+    *cs = pxl_fm_flip_if_bit1(odd ? sv : cv, q + 1);
+    return true;
 }

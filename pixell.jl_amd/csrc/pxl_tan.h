@@ -4,12 +4,11 @@
 // ------------------------------------------------------------------------------------------------
 // Gnomonic (A16), tan_proj.jl:44-75
 // ------------------------------------------------------------------------------------------------
-// These are tolerance-checked paths (FP64 transcendentals: pxl_fastmath.h's atan2 / asin / rsqrt, <= 1.5 ulp, and the device
-// library's sincos, vs glibc), held to the reference's own bar for
+// These are tolerance-checked paths (FP64 transcendentals: pxl_fastmath.h's atan2 / asin / sincos / rsqrt, <= 1.5 ulp, vs glibc), held to the reference's own bar for
 // its fast Gnomonic code against wcslib: sum |difference| < 1e-9 over the 1827 x 1825 posmap (test_geometry.jl:116-119).
 //
 // sky2pix keeps the reference's operations one for one; each angle's sine and cosine come from ONE sincos (one
-// argument reduction instead of two; the library's: a sincos of our own, with or without reduction, measured slower -- DESIGN 4b) and the loop-invariant scale / unit is divided once on the host (a correctly
+// argument reduction instead of two; pxl_fastmath.h's for angles below 2^19 pi/2, the library's beyond) and the loop-invariant scale / unit is divided once on the host (a correctly
 // rounded quotient either way).
 //
 // pix2sky is evaluated in an algebraically equal form without the intermediate angles.  The reference
@@ -38,8 +37,12 @@ static TanParams tan_setup(const pxl_car_wcs& w) {
 }
 __device__ inline void tan_sky2pix(const TanParams& t, double a, double d, double* x, double* y) {
     double sd, cd, sa, ca;
-    sincos(d, &sd, &cd);
-    sincos(a - t.a0, &sa, &ca);
+    const double da = a - t.a0;
+    const bool fast = (int)pxl_fm_sincos(d, &sd, &cd) & (int)pxl_fm_sincos(da, &sa, &ca);    // |angle| <= 2^19 pi/2: <= 1.5 ulp, ~40 instructions each
+    if (__builtin_expect(!fast, 0)) {                                                // huge or non-finite angles: the library
+        sincos(d, &sd, &cd);
+        sincos(da, &sa, &ca);
+    }
     double A = cd * ca;
     double F = t.su / (t.sd0 * sd + A * t.cd0);
     double LINE = -F * (t.cd0 * sd - A * t.sd0);

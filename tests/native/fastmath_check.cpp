@@ -52,6 +52,21 @@ int main(int argc, char** argv) {
             if (er > e_rsqrt) { e_rsqrt = er; w_rsqrt = uu; }
         }
     }
+    // sincos: |x| <= 8 (the evaluators' range), near multiples of pi/2, and up to the limit of the fast path
+    double e_sin = 0, e_cos = 0, e_sin_big = 0, e_cos_big = 0, w_sin = 0, w_cos = 0;
+    for (long k = 0; k < n; ++k) {
+        double xs = (U(rng) * 2 - 1) * 8;
+        if ((k & 3) == 1) xs = std::round((U(rng) * 2 - 1) * 16) * (M_PI / 2) + (U(rng) - 0.5) * std::exp2(-U(rng) * 30);
+        double sn, cs;
+        if (!pxl_fm_sincos(xs, &sn, &cs)) { printf("{\"error\": \"fast path refused %g\"}\n", xs); return 1; }
+        double es = err_ulp(sn, sinl((long double)xs)), ec = err_ulp(cs, cosl((long double)xs));
+        if (es > e_sin) { e_sin = es; w_sin = xs; }
+        if (ec > e_cos) { e_cos = ec; w_cos = xs; }
+        double xl = (U(rng) * 2 - 1) * 823549.0;
+        if (!pxl_fm_sincos(xl, &sn, &cs)) { printf("{\"error\": \"fast path refused %g\"}\n", xl); return 1; }
+        e_sin_big = std::max(e_sin_big, err_ulp(sn, sinl((long double)xl)));
+        e_cos_big = std::max(e_cos_big, err_ulp(cs, cosl((long double)xl)));
+    }
     // special cases: bit-for-bit what libm returns
     const double inf = INFINITY, nan = NAN;
     const double sp[] = {0.0, -0.0, 1.0, -1.0, inf, -inf, nan, 5e-324, -5e-324, 1e308, -1e308, 0.5, 0.75, 2.0};
@@ -67,9 +82,15 @@ int main(int argc, char** argv) {
         double g = pxl_fm_asin(v), w = std::asin(v);
         if (!(same_bits(g, w) || err_ulp(g, asinl((long double)v)) <= 1.0) || (!std::isnan(w) && std::signbit(g) != std::signbit(w))) { ++special_bad; fprintf(stderr, "asin(%g) = %a, libm %a\n", v, g, w); }
     }
+    {
+        double sn = 7, cs = 7;
+        if (pxl_fm_sincos(1e6, &sn, &cs) || pxl_fm_sincos(inf, &sn, &cs) || pxl_fm_sincos(nan, &sn, &cs) || sn != 7 || cs != 7) ++special_bad;
+        pxl_fm_sincos(0.0, &sn, &cs);
+        if (!(sn == 0.0 && cs == 1.0)) ++special_bad;
+    }
     printf("{\"samples\": %ld, \"atan2_max_ulp\": %.3f, \"atan2_worst\": [%.17g, %.17g], \"asin_max_ulp\": %.3f, \"asin_worst\": %.17g, "
-           "\"rsqrt_max_ulp\": %.3f, "
+           "\"sin_max_ulp\": %.3f, \"sin_worst\": %.17g, \"cos_max_ulp\": %.3f, \"cos_worst\": %.17g, \"sin_max_ulp_big\": %.3f, \"cos_max_ulp_big\": %.3f, \"rsqrt_max_ulp\": %.3f, "
            "\"rsqrt_worst\": %.17g, \"special_bad\": %d}\n",
-           n, e_atan2, w_atan2[0], w_atan2[1], e_asin, w_asin, e_rsqrt, w_rsqrt, special_bad);
+           n, e_atan2, w_atan2[0], w_atan2[1], e_asin, w_asin, e_sin, w_sin, e_cos, w_cos, e_sin_big, e_cos_big, e_rsqrt, w_rsqrt, special_bad);
     return 0;
 }

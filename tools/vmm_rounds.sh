@@ -1,10 +1,10 @@
 #!/bin/bash
 set -o pipefail
-timeout -k 10 400 python -m pytest tests/test_gpu_entrypoints.py -x -q -m gpu -k native 2>&1 | tail -3
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -I include tools/native/native_bench.cpp -L pixell.jl_amd -lpixell_hip -Wl,-rpath,$PWD/pixell.jl_amd -o /tmp/native_bench || exit 1
-for rnd in 1 2; do
-  /tmp/native_bench 21600 1 refine 20 | tee -a gpurun_out/r03_native_host_placed.jsonl
-  /tmp/native_bench 21600 1 refine 20 placed | tee -a gpurun_out/r03_native_host_placed.jsonl
-  /tmp/native_bench 43200 3 same 10 | tee -a gpurun_out/r03_native_host_placed.jsonl
-  /tmp/native_bench 43200 3 same 10 placed | tee -a gpurun_out/r03_native_host_placed.jsonl
+timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "gnomonic or generic or tan" 2>&1 | tail -2
+for rnd in 1 2 3; do
+  PXL_LIB_PATH=$PWD/tools/native/libpixell_hip_prev.so timeout -k 10 200 python tools/bench_tan_evaluators.py 2>/dev/null | grep sky2pix | sed 's/^{/{"build": "library sincos", /' >> gpurun_out/r03_fm_sincos_ab.jsonl || exit 1
+  timeout -k 10 200 python tools/bench_tan_evaluators.py 2>/dev/null | grep sky2pix | sed 's/^{/{"build": "pxl_fm_sincos", /' >> gpurun_out/r03_fm_sincos_ab.jsonl || exit 1
 done
+PXL_LIB_PATH=$PWD/tools/native/libpixell_hip_prev.so timeout -k 10 200 python tools/bench_tan_mosaic.py 2>/dev/null | grep variant | cut -c1-200 | sed 's/^{/{"build": "library sincos", /' >> gpurun_out/r03_fm_sincos_ab.jsonl
+timeout -k 10 200 python tools/bench_tan_mosaic.py 2>/dev/null | grep variant | cut -c1-200 | sed 's/^{/{"build": "pxl_fm_sincos", /' >> gpurun_out/r03_fm_sincos_ab.jsonl
+cat gpurun_out/r03_fm_sincos_ab.jsonl
