@@ -874,6 +874,22 @@ def gpu_evaluators(dev):
     nb = n // 2
     rec("pix2sky!(safe=true)", _median_ms(lambda: pj.pix2sky_(g, pix[:nb], sky[:nb], safe=True), dev, reps=5), 32.0 * nb, nb, "Mpts_s",
         "car_proj.jl:92-122 with unwind! (enmap_ops.jl:26-32), 2xN, 1e8 points")
+    del pix, sky
+    torch.cuda.empty_cache()
+    # the Gnomonic evaluators (tan_proj.jl:44-75: two N-vectors in, two out) and the Gnomonic posmap of an 8192^2 patch of 0.5' pixels
+    N = 8192
+    tan = pj.Gnomonic((-0.5 / 60, 0.5 / 60), (N / 2 + 0.5, N / 2 + 0.5), (40.0, -25.0))
+    tg = ((N, N), tan)
+    nt = 100_000_000
+    ip = torch.empty(nt, dtype=torch.float64, device=dev).uniform_(1.0, float(N))
+    jp = torch.empty(nt, dtype=torch.float64, device=dev).uniform_(1.0, float(N))
+    tra, tdec = pj.pix2sky(tg, ip, jp, safe=False)
+    rec("Gnomonic pix2sky(i, j)", _median_ms(lambda: pj.pix2sky(tg, ip, jp, safe=False), dev, reps=5), 32.0 * nt, nt, "Mpts_s",
+        "tan_proj.jl:59-75, two N-vectors, 1e8 points, FP64-transcendental bound (pxl_fastmath.h)")
+    rec("Gnomonic sky2pix(ra, dec)", _median_ms(lambda: pj.sky2pix(tg, tra, tdec, safe=False), dev, reps=5), 32.0 * nt, nt, "Mpts_s",
+        "tan_proj.jl:44-57, two N-vectors, 1e8 points")
+    rec("Gnomonic posmap 8192^2", _median_ms(lambda: pj.posmap((N, N), tan, device=dev), dev, reps=5), 16.0 * N * N, N * N, "Mpix_s",
+        "enmap_ops.jl:190-203 on a Gnomonic WCS, write-only 16 B/pixel")
     return out
 
 
