@@ -25,9 +25,10 @@ def test_gpus_n_without_torchrun_starts_its_own_ranks():
     assert "must be launched with" not in r.stderr + r.stdout
     assert "starting 2 ranks" in r.stderr
     if not torch.cuda.is_available():
-        # both ranks ran bench.py's main() and refused to run without the GPU; the job's code came back
+        # the ranks ran bench.py's main() and refused to run without the GPU; the job's code came back.  (torchrun tears the job
+        # down as soon as one rank fails, so the second rank does not always get to print its own refusal.)
         assert r.returncode != 0
-        assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]
+        assert r.stderr.count("bench.py needs an MI355X") >= 1, r.stderr[-2000:]
         assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
