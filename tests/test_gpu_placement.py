@@ -36,7 +36,7 @@ def test_map_classes_and_place_pair(pj, O, dev):
     offs, labels, info = pj.map_classes(arena, step_gib=2)
     assert len(offs) == len(labels) == 6 and labels[0] == 0 and 1 <= info["classes"] <= 6
     # within a class the probe runs at 5.6-5.9 TB/s, across classes at 6.6-7.0 TB/s: 2 GiB in 300-400 us
-    assert 250 < info["probe_us_same_class"] < 480
+    assert 150 < info["probe_us_same_class"] < 1500          # order of magnitude only: a timing, on whatever box runs the test
     del arena
     shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 2400, dims=(2,))
     shape_out, wcs_out = pj.fullsky_geometry(2 * math.pi / 4800)
