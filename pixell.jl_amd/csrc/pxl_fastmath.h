@@ -81,6 +81,8 @@ PXL_FM_HD double pxl_fm_rcp_seed(double w) {
 }
 
 // 1/sqrt(u) for u in [2^-1000, 2^1000] to ~1 ulp: seed y0 (relative error e0 <= 2^-20), then y0 (1 + e/2 + 3 e^2/8), e = 1 - u y0^2
+// Domain: finite u > 0.  +Inf gives NaN (Inf * 0 in the refinement) -- deliberately: the evaluators multiply the result by a
+// numerator that overflows together with u, and a quiet 0 there would turn into a wrong finite angle.
 PXL_FM_HD double pxl_fm_rsqrt(double u) {
     const double y0 = pxl_fm_rsq_seed(u);
     const double e = __builtin_fma(-(u * y0), y0, 1.0);

@@ -56,6 +56,10 @@ __device__ inline TanRow tan_row(const TanParams& t, double j) {
     const double Y = (t.cpy - j) * t.uos;
     return TanRow{Y * Y, t.sd0 * Y + t.cd0, t.sd0 - t.cd0 * Y};
 }
+// Domain note: plane coordinates whose squares overflow (|pixel offset| * pixel size beyond 1e150 rad) or that are infinite give
+// NaN in DEC here (Inf * 0 inside the reciprocal square root), where the reference's sequence of angles happens to leave a finite
+// number; RA keeps the reference's limit.  NaN in, NaN out.  (Routing such points through the reference's own operation order
+// inside the kernel was built and dropped: the out-of-line call costs the hot path 24 VGPRs and a stack frame.)
 __device__ inline void tan_pix2sky_xrow(const TanParams& t, const TanRow& r, double X, double XX, double* a, double* d) {
     const double rs = pxl_fm_rsqrt(1.0 + (XX + r.Y2));
     *a = t.a0 + pxl_fm_atan2(-X, r.den);

@@ -88,6 +88,7 @@ int main(int argc, char** argv) {
         pxl_fm_sincos(0.0, &sn, &cs);
         if (!(sn == 0.0 && cs == 1.0)) ++special_bad;
     }
+    if (!(std::isnan(pxl_fm_rsqrt(inf)) && std::isnan(pxl_fm_rsqrt(nan)) && pxl_fm_rsqrt(4.0) == 0.5)) ++special_bad;
     printf("{\"samples\": %ld, \"atan2_max_ulp\": %.3f, \"atan2_worst\": [%.17g, %.17g], \"asin_max_ulp\": %.3f, \"asin_worst\": %.17g, "
            "\"sin_max_ulp\": %.3f, \"sin_worst\": %.17g, \"cos_max_ulp\": %.3f, \"cos_worst\": %.17g, \"sin_max_ulp_big\": %.3f, \"cos_max_ulp_big\": %.3f, \"rsqrt_max_ulp\": %.3f, "
            "\"rsqrt_worst\": %.17g, \"special_bad\": %d}\n",

@@ -922,6 +922,21 @@ def test_gnomonic_wide_fields_on_device(pj, O, dev):
         r = rad * np.radians(1.0 / 60)             # plane radius; d(pixel)/d(angle) grows like 1 + r^2 towards the horizon
         tol = 1e-9 + 2e-14 * rad * (1.0 + r * r)
         assert (np.abs(x.cpu().numpy() - ex) < tol).all() and (np.abs(y.cpu().numpy() - ey) < tol).all()
+    # non-finite and absurd pixel coordinates: NaN in, NaN out; where the plane radius overflows or is infinite the device gives
+    # NaN in DEC (documented in pxl_tan.h) or the oracle's number, never another finite one
+    wcs = pj.Gnomonic((-1.0 / 60, 1.0 / 60), (1000.5, 900.5), (30.0, 20.0))
+    ip = np.array([np.nan, 5.0, np.inf, -np.inf, 7.0, 1e200, -1e300, 3.0, np.nan, 1e15])
+    jp = np.array([4.0, np.nan, 6.0, 8.0, np.inf, 2.0, 9.0, -1e250, np.nan, -1e15])
+    ra, dec = pj.pix2sky(((2000, 1800), wcs), to_dev(ip, dev), to_dev(jp, dev), safe=False)
+    era, edec = O.pix2sky_tan(wcs, ip, jp)
+    ra, dec = ra.cpu().numpy(), dec.cpu().numpy()
+    wild = ~(np.abs(jp) < 1e150) | ~(np.abs(ip) < 1e150)
+    for got, exp in ((ra, era), (dec, edec)):
+        assert np.isnan(got[np.isnan(exp)]).all(), (got, exp)
+        ok = ~np.isnan(exp) & ~wild
+        assert np.abs(got[ok] - exp[ok]).max() < 1e-9, (got, exp)
+        w = ~np.isnan(exp) & wild
+        assert (np.isnan(got[w]) | (np.abs(got[w] - exp[w]) < 1e-9)).all(), (got, exp)
     # angles many periods away from the centre, and beyond the fast sincos range (the library path)
     wcs = pj.Gnomonic((-1.0 / 60, 1.0 / 60), (1000.5, 900.5), (30.0, 20.0))
     base_ra, base_dec = np.radians(30.0) + rng.uniform(-0.3, 0.3, 4096), np.radians(20.0) + rng.uniform(-0.3, 0.3, 4096)
