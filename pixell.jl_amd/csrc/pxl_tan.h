@@ -62,7 +62,10 @@ __device__ inline TanRow tan_row(const TanParams& t, double j) {
 // inside the kernel was built and dropped: the out-of-line call costs the hot path 24 VGPRs and a stack frame.)
 __device__ inline void tan_pix2sky_xrow(const TanParams& t, const TanRow& r, double X, double XX, double* a, double* d) {
     const double rs = pxl_fm_rsqrt(1.0 + (XX + r.Y2));
-    *a = t.a0 + pxl_fm_atan2(-X, r.den);
+    // in front of the tangent plane's horizon with ordinary magnitudes (every lane of the wave: one vote) atan2 needs none of
+    // its infinity / scaling / negative-x / NaN steps -- a sixth of its instructions; same bits either way
+    if (__all(pxl_fm_atan2_is_tame(-X, r.den))) *a = t.a0 + pxl_fm_atan2<true>(-X, r.den);
+    else                                        *a = t.a0 + pxl_fm_atan2<false>(-X, r.den);
     *d = pxl_fm_asin(r.num * rs);
 }
 __device__ inline void tan_pix2sky_row(const TanParams& t, const TanRow& r, double i, double* a, double* d) {

@@ -28,6 +28,7 @@ int main(int argc, char** argv) {
     std::uniform_real_distribution<double> U(0.0, 1.0);
     double e_atan2 = 0, e_asin = 0;
     double w_atan2[2] = {0, 0}, w_asin = 0, e_rsqrt = 0, w_rsqrt = 0;
+    long n_tame = 0, tame_bad = 0;
     for (long k = 0; k < n; ++k) {
         // atan2: angles uniform on the circle (and clustered at the octant / interval boundaries), radii over 600 binades
         double ang = (k & 1) ? (U(rng) * 2 - 1) * M_PI : std::round(U(rng) * 64) * (M_PI / 32) + (U(rng) - 0.5) * 1e-6;
@@ -35,8 +36,12 @@ int main(int argc, char** argv) {
         if ((k & 7) == 5) ang = M_PI / 8 + (U(rng) - 0.5) * 1e-9;
         double rad = std::exp2((U(rng) - 0.5) * 600);
         double y = rad * std::sin(ang), x = rad * std::cos(ang);
-        double e = err_ulp(pxl_fm_atan2(y, x), atan2l((long double)y, (long double)x));
+        const double got = pxl_fm_atan2(y, x);
+        double e = err_ulp(got, atan2l((long double)y, (long double)x));
         if (e > e_atan2) { e_atan2 = e; w_atan2[0] = y; w_atan2[1] = x; }
+        // the TAME form gives the same bits wherever its precondition holds, and the precondition test refuses everything else
+        if (pxl_fm_atan2_is_tame(y, x)) { ++n_tame; if (!same_bits(pxl_fm_atan2<true>(y, x), got)) ++tame_bad; }
+        else if (x > 0 && std::isfinite(y) && std::fmax(std::fabs(x), std::fabs(y)) >= 0x1p-700 && std::fmax(std::fabs(x), std::fabs(y)) <= 0x1p+700) ++tame_bad;
         // asin: uniform, clustered at 0, 1/2 and 1
         double v = U(rng) * 2 - 1;
         if ((k & 3) == 1) v = std::copysign(0.5 + (U(rng) - 0.5) * 1e-3, v);
@@ -88,10 +93,15 @@ int main(int argc, char** argv) {
         pxl_fm_sincos(0.0, &sn, &cs);
         if (!(sn == 0.0 && cs == 1.0)) ++special_bad;
     }
+    for (double y : sp)
+        for (double x : sp)
+            if (pxl_fm_atan2_is_tame(y, x) && !same_bits(pxl_fm_atan2<true>(y, x), pxl_fm_atan2(y, x))) ++tame_bad;
+    if (pxl_fm_atan2_is_tame(1.0, inf) || pxl_fm_atan2_is_tame(nan, 1.0) || pxl_fm_atan2_is_tame(1.0, nan) || pxl_fm_atan2_is_tame(1.0, -1.0) ||
+        pxl_fm_atan2_is_tame(1.0, 0.0) || pxl_fm_atan2_is_tame(inf, 1.0) || pxl_fm_atan2_is_tame(1e-300, 1e-300)) ++tame_bad;
     if (!(std::isnan(pxl_fm_rsqrt(inf)) && std::isnan(pxl_fm_rsqrt(nan)) && pxl_fm_rsqrt(4.0) == 0.5)) ++special_bad;
     printf("{\"samples\": %ld, \"atan2_max_ulp\": %.3f, \"atan2_worst\": [%.17g, %.17g], \"asin_max_ulp\": %.3f, \"asin_worst\": %.17g, "
            "\"sin_max_ulp\": %.3f, \"sin_worst\": %.17g, \"cos_max_ulp\": %.3f, \"cos_worst\": %.17g, \"sin_max_ulp_big\": %.3f, \"cos_max_ulp_big\": %.3f, \"rsqrt_max_ulp\": %.3f, "
-           "\"rsqrt_worst\": %.17g, \"special_bad\": %d}\n",
-           n, e_atan2, w_atan2[0], w_atan2[1], e_asin, w_asin, e_sin, w_sin, e_cos, w_cos, e_sin_big, e_cos_big, e_rsqrt, w_rsqrt, special_bad);
+           "\"rsqrt_worst\": %.17g, \"tame_samples\": %ld, \"tame_bad\": %ld, \"special_bad\": %d}\n",
+           n, e_atan2, w_atan2[0], w_atan2[1], e_asin, w_asin, e_sin, w_sin, e_cos, w_cos, e_sin_big, e_cos_big, e_rsqrt, w_rsqrt, n_tame, tame_bad, special_bad);
     return 0;
 }
