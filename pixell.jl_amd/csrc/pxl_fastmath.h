@@ -144,11 +144,17 @@ PXL_FM_HD double pxl_fm_atan2(double y, double x) {
     return (x != x || y != y) ? x + y : a;
 }
 
-// asin(v); NaN outside [-1, 1]
+// asin(v); NaN outside [-1, 1].  HALF (compile time): 0 = any v (both halves evaluated, one selected); 1 = the caller guarantees
+// |v| <= 1/2, 2 = |v| > 1/2 or NaN (it has tested a whole wave): only that half is evaluated -- the same operations, the same bits.
+template <int HALF = 0>
 PXL_FM_HD double pxl_fm_asin(double v) {
     constexpr double R[PXL_FM_ASIN_R_N] = PXL_FM_ASIN_R;
     const double av = __builtin_fabs(v);
-    const bool big = av > 0.5;
+    if (HALF == 1) {
+        const double z = v * v;
+        return __builtin_copysign(av + (av * z) * pxl_fm_horner(R, z), v);
+    }
+    const bool big = HALF == 2 || av > 0.5;
     // big: asin(av) = pi/2 - 2 asin(sqrt(w)), w = (1 - av) / 2 (exact for av in (1/2, 1], and then in [2^-54, 1/4) or 0)
     const double w = __builtin_fma(-0.5, av, 0.5);
     // sqrt(w) = b + blo: one Goldschmidt step from the seed, then two corrections by the exact residual w - s^2
@@ -166,6 +172,7 @@ PXL_FM_HD double pxl_fm_asin(double v) {
     const double u = PXL_FM_PIO2_1 - b2;
     const double uerr = (PXL_FM_PIO2_1 - u) - b2;
     const double rbig = u + (uerr - (((blo + p) + (blo + p)) - PXL_FM_PIO2_2));
+    if (HALF == 2) return __builtin_copysign(rbig, v);
     const double rsmall = av + p;
     return __builtin_copysign(big ? rbig : rsmall, v);
 }

@@ -28,7 +28,7 @@ int main(int argc, char** argv) {
     std::uniform_real_distribution<double> U(0.0, 1.0);
     double e_atan2 = 0, e_asin = 0;
     double w_atan2[2] = {0, 0}, w_asin = 0, e_rsqrt = 0, w_rsqrt = 0;
-    long n_tame = 0, tame_bad = 0;
+    long n_tame = 0, tame_bad = 0, half_bad = 0;
     for (long k = 0; k < n; ++k) {
         // atan2: angles uniform on the circle (and clustered at the octant / interval boundaries), radii over 600 binades
         double ang = (k & 1) ? (U(rng) * 2 - 1) * M_PI : std::round(U(rng) * 64) * (M_PI / 32) + (U(rng) - 0.5) * 1e-6;
@@ -47,8 +47,11 @@ int main(int argc, char** argv) {
         if ((k & 3) == 1) v = std::copysign(0.5 + (U(rng) - 0.5) * 1e-3, v);
         if ((k & 3) == 2) v = std::copysign(1.0 - U(rng) * U(rng) * 1e-2, v);
         if ((k & 15) == 7) v = std::exp2(-U(rng) * 60) * (v < 0 ? -1 : 1);
-        e = err_ulp(pxl_fm_asin(v), asinl((long double)v));
+        const double gasin = pxl_fm_asin(v);
+        e = err_ulp(gasin, asinl((long double)v));
         if (e > e_asin) { e_asin = e; w_asin = v; }
+        // the one-half forms give the bits of the general one
+        if (!same_bits(std::fabs(v) <= 0.5 ? pxl_fm_asin<1>(v) : pxl_fm_asin<2>(v), gasin)) ++half_bad;
         // rsqrt: the evaluators call it on 1 + X^2 + Y^2; here over 200 binades
         {
             double uu = std::exp2((U(rng) - 0.5) * 200);
@@ -98,10 +101,12 @@ int main(int argc, char** argv) {
             if (pxl_fm_atan2_is_tame(y, x) && !same_bits(pxl_fm_atan2<true>(y, x), pxl_fm_atan2(y, x))) ++tame_bad;
     if (pxl_fm_atan2_is_tame(1.0, inf) || pxl_fm_atan2_is_tame(nan, 1.0) || pxl_fm_atan2_is_tame(1.0, nan) || pxl_fm_atan2_is_tame(1.0, -1.0) ||
         pxl_fm_atan2_is_tame(1.0, 0.0) || pxl_fm_atan2_is_tame(inf, 1.0) || pxl_fm_atan2_is_tame(1e-300, 1e-300)) ++tame_bad;
+    for (double v : {0.0, -0.0, 0.5, -0.5, 5e-324, 1e-200}) if (!same_bits(pxl_fm_asin<1>(v), pxl_fm_asin(v))) ++half_bad;
+    for (double v : {1.0, -1.0, 0.5000000000000001, 1.0000000000000002, -1.5, (double)inf, (double)nan}) if (!same_bits(pxl_fm_asin<2>(v), pxl_fm_asin(v))) ++half_bad;
     if (!(std::isnan(pxl_fm_rsqrt(inf)) && std::isnan(pxl_fm_rsqrt(nan)) && pxl_fm_rsqrt(4.0) == 0.5)) ++special_bad;
     printf("{\"samples\": %ld, \"atan2_max_ulp\": %.3f, \"atan2_worst\": [%.17g, %.17g], \"asin_max_ulp\": %.3f, \"asin_worst\": %.17g, "
            "\"sin_max_ulp\": %.3f, \"sin_worst\": %.17g, \"cos_max_ulp\": %.3f, \"cos_worst\": %.17g, \"sin_max_ulp_big\": %.3f, \"cos_max_ulp_big\": %.3f, \"rsqrt_max_ulp\": %.3f, "
-           "\"rsqrt_worst\": %.17g, \"tame_samples\": %ld, \"tame_bad\": %ld, \"special_bad\": %d}\n",
-           n, e_atan2, w_atan2[0], w_atan2[1], e_asin, w_asin, e_sin, w_sin, e_cos, w_cos, e_sin_big, e_cos_big, e_rsqrt, w_rsqrt, n_tame, tame_bad, special_bad);
+           "\"rsqrt_worst\": %.17g, \"tame_samples\": %ld, \"tame_bad\": %ld, \"asin_half_bad\": %ld, \"special_bad\": %d}\n",
+           n, e_atan2, w_atan2[0], w_atan2[1], e_asin, w_asin, e_sin, w_sin, e_cos, w_cos, e_sin_big, e_cos_big, e_rsqrt, w_rsqrt, n_tame, tame_bad, half_bad, special_bad);
     return 0;
 }

@@ -356,7 +356,10 @@ def fuzz_maps(rng):
     era, edec = O.pix2sky_tan(wcs, ii.ravel(), jj.ravel())
     gra, gdec = ra.data.cpu().numpy().ravel(), dec.data.cpu().numpy().ravel()
     dra = np.abs(np.angle(np.exp(1j * (gra - era))))            # RA compared on the circle
-    assert np.nanmax(dra) < 1e-11 and np.nanmax(np.abs(gdec - edec)) < 1e-11, ("tan posmap", (nx, ny), wcs, float(np.nanmax(dra)), float(np.nanmax(np.abs(gdec - edec))))
+    # both sides take asin / atan2 of direction cosines: an ulp there is 1e-16 / cos(dec) in the angle, so a pixel within arc seconds
+    # of a celestial pole (found by seed 5151: a patch centred at dec 88.4 degrees, 1.3e-11) needs the bound scaled with it
+    tol = 1e-11 + 4e-16 / np.maximum(np.cos(edec), 1e-12)
+    assert np.nanmax(dra - tol) < 0 and np.nanmax(np.abs(gdec - edec) - tol) < 0, ("tan posmap", (nx, ny), wcs, float(np.nanmax(dra)), float(np.nanmax(np.abs(gdec - edec))))
     assert np.array_equal(np.isnan(gra), np.isnan(era))
     return "tan_posmap"
 
