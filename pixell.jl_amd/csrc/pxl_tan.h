@@ -69,10 +69,11 @@ __device__ inline void tan_pix2sky_xrow(const TanParams& t, const TanRow& r, dou
     if (__all(pxl_fm_atan2_is_tame(-X, r.den))) *a = t.a0 + pxl_fm_atan2<true>(-X, r.den);
     else                                        *a = t.a0 + pxl_fm_atan2<false>(-X, r.den);
     // likewise asin on a grid: a wave whose sines are all within 1/2 (|dec| <= 30 degrees), or all beyond, evaluates that half
-    // only (posmap 0.35-0.38 -> 0.30-0.33 ms; scattered points mix the halves in most waves and lose 3 % to the votes: not there)
+    // only (posmap 0.35-0.38 -> 0.30-0.33 ms).  Scattered points of a wide patch mix the halves in most waves, and two votes cost
+    // them 3 %: they take the |v| <= 1/2 vote alone (neutral on a 68-degree patch, 62 -> 69 % on a 4-degree one)
     const double sv = r.num * rs;
     const bool small = fabs(sv) <= 0.5;
-    if (GRID && __all(small))       *d = pxl_fm_asin<1>(sv);
+    if (__all(small))               *d = pxl_fm_asin<1>(sv);         // also for scattered points: patches within 30 degrees of the equator
     else if (GRID && __all(!small)) *d = pxl_fm_asin<2>(sv);
     else                            *d = pxl_fm_asin<0>(sv);
 }
