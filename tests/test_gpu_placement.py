@@ -152,6 +152,12 @@ def test_native_pair_alloc_through_the_abi(pj, dev):
     gc.collect()
     free1, _ = torch.cuda.mem_get_info(dev)
     assert free1 >= free0 - (1 << 30)                                   # the allocation went back to the driver
+    # a pair too small to map (no head-room, below 2 GiB): the plain layout, source first, both 2 MiB aligned, freed again
+    tiny = pj._lib.MemPair()
+    assert lib.pxl_mem_pair_alloc(3 << 20, (5 << 20) + 8, 0, C.byref(tiny), None) == 0
+    assert tiny.src == tiny.arena and tiny.dst == tiny.arena + tiny.dst_offset and tiny.dst_offset >= (3 << 20)
+    assert tiny.arena_bytes == (4 << 20) + (6 << 20) and tiny.classes == 1 and tiny.dst_two_classes == 0 and tiny.probes == 0
+    assert lib.pxl_mem_pair_free(C.byref(tiny)) == 0 and not tiny.arena and not tiny.src
     bad = pj._lib.MemPair()
     assert lib.pxl_mem_pair_alloc(0, 1 << 20, 0, C.byref(bad), None) != 0
     assert lib.pxl_mem_pair_alloc(1 << 20, 1 << 20, 0, None, None) != 0
