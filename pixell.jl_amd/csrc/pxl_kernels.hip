@@ -486,9 +486,13 @@ int pxl_posmap_car_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64_t r
     if (nrows == 0) return PXL_OK;
     if (!ra || !dec) return fail(PXL_EINVAL, "posmap: null output");
     if (nrows > 65535LL * PXL_POS_ROWS) return fail(PXL_EINVAL, "posmap: more than %lld rows per call", 65535LL * PXL_POS_ROWS);
-    dim3 grid((unsigned)(((shape[0] + 1) / 2 + 255) / 256), (unsigned)((nrows + PXL_POS_ROWS - 1) / PXL_POS_ROWS));
+    const int64_t nych = (nrows + PXL_POS_ROWS - 1) / PXL_POS_ROWS;
+    int fronts = env_int("PXL_POSMAP_FRONTS", 8);
+    if (fronts < 1 || nych < 16 * fronts) fronts = 1;
+    const int64_t per = (nych + fronts - 1) / fronts;
+    dim3 grid((unsigned)(((shape[0] + 1) / 2 + 255) / 256), (unsigned)(per * fronts));
     hipLaunchKernelGGL(k_posmap_car, grid, dim3(256), 0, (hipStream_t)stream,
-                       car_affine(*wcs), shape[0], row0, nrows, ra, dec, safe ? 1 : 0);
+                       car_affine(*wcs), shape[0], row0, nrows, ra, dec, safe ? 1 : 0, fronts);
     return check_launch("k_posmap_car");
 }
 
@@ -502,8 +506,12 @@ int pxl_pixareamap_car_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64
     if ((shape[0] & 1) == 0 && ((uintptr_t)area & 15) == 0 && env_int("PXL_AREA_ROWS", 0) == 0) {
         // one contiguous chunk of the map per block (pairs of pixels, 16-byte stores)
         const int64_t total = shape[0] / 2 * nrows;
-        hipLaunchKernelGGL(k_pixareamap_chunks, dim3((unsigned)((total + PXL_AREA_CHUNK - 1) / PXL_AREA_CHUNK)), dim3(256), 0,
-                           (hipStream_t)stream, car_affine(*wcs), shape[0], row0, nrows, area);
+        const int64_t nchunks = (total + PXL_AREA_CHUNK - 1) / PXL_AREA_CHUNK;
+        int fronts = env_int("PXL_AREA_FRONTS", 8);
+        if (fronts < 1 || nchunks < 64 * fronts) fronts = 1;
+        const int64_t per = (nchunks + fronts - 1) / fronts;
+        hipLaunchKernelGGL(k_pixareamap_chunks, dim3((unsigned)(per * fronts)), dim3(256), 0,
+                           (hipStream_t)stream, car_affine(*wcs), shape[0], row0, nrows, area, fronts);
         return check_launch("k_pixareamap_chunks");
     }
     // odd nx / unaligned map: one row per blockIdx.y (<= 65535 per launch)

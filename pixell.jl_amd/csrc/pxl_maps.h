@@ -7,15 +7,20 @@
 // Block = (512-column chunk, chunk of rows): RA (rewound) is computed once per lane and reused for every
 // row of the chunk; DEC / the row area is one evaluation per row.
 #define PXL_POS_ROWS 32
+// `fronts`: the row chunks are dealt so that chunk row y works in part y % fronts of each map -- several write fronts per map
+// instead of one (a write-only stream takes them faster: see k_pixareamap_chunks).
 __global__ __launch_bounds__(256) void k_posmap_car(CarAffine c, int64_t nx, int64_t row0, int64_t nrows,
-                                                    double* __restrict__ ra, double* __restrict__ dec, int safe) {
+                                                    double* __restrict__ ra, double* __restrict__ dec, int safe, int fronts) {
     const bool vec = ((nx & 1) == 0) && ((((uintptr_t)ra | (uintptr_t)dec) & 15) == 0);
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;        // 0-based column of the pair
     if (i >= nx) return;
     double a0 = p2s_ra(c, (double)(i + 1));
     double a1 = p2s_ra(c, (double)(i + 2));
     if (safe) { a0 = rewind(a0, PXL_TWOPI_D, 0.0); a1 = rewind(a1, PXL_TWOPI_D, 0.0); }
-    const int64_t jr0 = (int64_t)blockIdx.y * PXL_POS_ROWS;
+    const int64_t per = (gridDim.y + fronts - 1) / fronts;
+    const int64_t yy = fronts > 1 ? (int64_t)(blockIdx.y % fronts) * per + blockIdx.y / fronts : (int64_t)blockIdx.y;
+    const int64_t jr0 = yy * PXL_POS_ROWS;
+    if (jr0 >= nrows) return;
     const int64_t jr1 = (jr0 + PXL_POS_ROWS < nrows) ? jr0 + PXL_POS_ROWS : nrows;
     for (int64_t jr = jr0; jr < jr1; ++jr) {
         double d = p2s_dec(c, (double)(row0 + jr + 1));
@@ -64,10 +69,15 @@ __device__ inline double pixarea_row(const CarAffine& c, double da, int64_t row0
     return (sin(d2) - sin(d1)) * da;
 }
 __global__ __launch_bounds__(256) void k_pixareamap_chunks(CarAffine c, int64_t nx, int64_t row0, int64_t nrows,
-                                                           double* __restrict__ area) {
+                                                           double* __restrict__ area, int fronts) {
     const double da = fabs(c.da);
     const int64_t npr = nx / 2, total = npr * nrows;
-    const int64_t t0 = (int64_t)blockIdx.x * PXL_AREA_CHUNK;
+    // FRONTS write fronts: the chunks are dealt so that block b writes in part b % FRONTS of the map (a write-only stream inside
+    // one memory class takes 2-8 fronts 11 % faster than one: profiles/r03_fronts_inside_one_class.jsonl)
+    const int64_t nchunks = gridDim.x, per = (nchunks + fronts - 1) / fronts;
+    const int64_t cidx = fronts > 1 ? (int64_t)(blockIdx.x % fronts) * per + blockIdx.x / fronts : (int64_t)blockIdx.x;
+    const int64_t t0 = cidx * PXL_AREA_CHUNK;
+    if (t0 >= total) return;
     int64_t jr = t0 / npr;
     int64_t next = (jr + 1) * npr;                           // first pair of the next row
     double v = pixarea_row(c, da, row0, jr);
