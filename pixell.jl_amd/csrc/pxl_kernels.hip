@@ -1171,11 +1171,15 @@ static int build_pairs_impl(const int64_t shape_in[3], const void* src, int64_t 
     const int64_t nx = shape_in[0], tiles = (src_nrows + 1 + PXL_POS_ROWS - 1) / PXL_POS_ROWS;
     if (tiles > 65535) return fail(PXL_EINVAL, "sample_build_pairs: more than %lld rows per call", 65535LL * PXL_POS_ROWS);
     const int64_t pitch = dtype == 4 ? PairGroup<float>::groups(nx) * PairGroup<float>::E : PairGroup<double>::groups(nx) * PairGroup<double>::E;
-    dim3 grid((unsigned)((pitch + 255) / 256), (unsigned)tiles, (unsigned)shape_in[2]);
+    int fronts = env_int("PXL_PAIRS_FRONTS", 8);
+    if (fronts < 1 || tiles < 16 * fronts) fronts = 1;
+    const int64_t per = (tiles + fronts - 1) / fronts;
+    if (per * fronts > 65535) fronts = 1;
+    dim3 grid((unsigned)((pitch + 255) / 256), (unsigned)(fronts > 1 ? per * fronts : tiles), (unsigned)shape_in[2]);
     if (dtype == 4)
-        hipLaunchKernelGGL((k_build_rowpairs<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, nx, src_nrows, (float2*)pairs);
+        hipLaunchKernelGGL((k_build_rowpairs<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, nx, src_nrows, (float2*)pairs, fronts);
     else
-        hipLaunchKernelGGL((k_build_rowpairs<double>), grid, dim3(256), 0, (hipStream_t)stream, (const double*)src, nx, src_nrows, (double2*)pairs);
+        hipLaunchKernelGGL((k_build_rowpairs<double>), grid, dim3(256), 0, (hipStream_t)stream, (const double*)src, nx, src_nrows, (double2*)pairs, fronts);
     return check_launch("k_build_rowpairs");
 }
 

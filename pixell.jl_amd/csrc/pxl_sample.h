@@ -383,7 +383,7 @@ template <typename T> struct PairGroup {
 };
 template <typename T>
 __global__ __launch_bounds__(256) void k_build_rowpairs(const T* __restrict__ src, int64_t nx, int64_t nrows,
-                                                        typename Vec2T<T>::type* __restrict__ pairs) {
+                                                        typename Vec2T<T>::type* __restrict__ pairs, int fronts) {
     // block = (256 entries of a pair row, PXL_POS_ROWS pair rows, component): a lane walks down its column carrying the
     // row above; stores are contiguous 2-element entries, loads run along the row with every (E-1)-th column read twice
     typedef typename Vec2T<T>::type T2;
@@ -397,7 +397,12 @@ __global__ __launch_bounds__(256) void k_build_rowpairs(const T* __restrict__ sr
     const int64_t c = blockIdx.z;
     const T* pl = src + c * nx * nrows;
     T2* out = pairs + c * pitch * (nrows + 1);
-    const int64_t p0 = (int64_t)blockIdx.y * PXL_POS_ROWS;
+    // the copy writes 8/3 of what it reads: like the other write-heavy kernels it deals its row tiles into `fronts` parts of the
+    // destination (tile row y works in part y % fronts) -- several write fronts instead of one
+    const int64_t per = (gridDim.y + fronts - 1) / fronts;
+    const int64_t yy = fronts > 1 ? (int64_t)(blockIdx.y % fronts) * per + blockIdx.y / fronts : (int64_t)blockIdx.y;
+    const int64_t p0 = yy * PXL_POS_ROWS;
+    if (p0 > nrows) return;
     const int64_t p1 = (p0 + PXL_POS_ROWS <= nrows) ? p0 + PXL_POS_ROWS : nrows + 1;     // pair rows [p0, p1)
     T above = (p0 >= 1) ? pl[(p0 - 1) * nx + i] : (T)0;
     for (int64_t p = p0; p < p1; ++p) {
