@@ -450,9 +450,13 @@ end
 # arrays keep from running by holding a reference to it)
 function place_pair_native(::Type{T}, src_dims::NTuple{N,Int}, dst_dims::NTuple{M,Int}; headroom::Integer=144 << 30) where {T,N,M}
     pair = MemPair()
-    check(ccall((:pxl_mem_pair_alloc, libpixell_hip), Cint, (UInt64, UInt64, UInt64, Ptr{Cvoid}, Ptr{Cvoid}),
-                prod(src_dims) * sizeof(T), prod(dst_dims) * sizeof(T), headroom, pointer_from_objref(pair), NULLSTREAM))
-    finalizer(p -> ccall((:pxl_mem_pair_free, libpixell_hip), Cint, (Ptr{Cvoid},), pointer_from_objref(p)), pair)
+    # pointer_from_objref gives a raw address the GC knows nothing about: the object must be rooted across the call
+    GC.@preserve pair begin
+        check(ccall((:pxl_mem_pair_alloc, libpixell_hip), Cint, (UInt64, UInt64, UInt64, Ptr{Cvoid}, Ptr{Cvoid}),
+                    prod(src_dims) * sizeof(T), prod(dst_dims) * sizeof(T), headroom, pointer_from_objref(pair), NULLSTREAM))
+    end
+    # (a finalizer's argument is rooted while it runs)
+    finalizer(p -> GC.@preserve(p, ccall((:pxl_mem_pair_free, libpixell_hip), Cint, (Ptr{Cvoid},), pointer_from_objref(p))), pair)
     return HIPArray{T,N}(Ptr{T}(pair.src), src_dims, pair), HIPArray{T,M}(Ptr{T}(pair.dst), dst_dims, pair), pair
 end
 

@@ -11,7 +11,7 @@
 //   pxl_fm_asin    one 13-term polynomial for both halves (|v| <= 1/2 directly, else pi/2 - 2 asin(sqrt((1 - |v|)/2)) with the
 //                  square root's residual carried along); <= 2 ulp measured
 //   pxl_fm_sincos  Cody-Waite reduction by pi/2 in two 53-bit parts (first step exact, second rounded once), 7- and 6-term
-//                  kernels, quadrant step = one swap and two sign flips; <= 1.5 ulp for |x| <= 2^19 pi/2, refused beyond (the
+//                  kernels, quadrant step = one swap and two sign flips; <= 1.5 ulp of max(|sin|, |cos|) (absolute) for |x| <= 2^19 pi/2, refused beyond (the
 //                  caller then uses the library).  A first version that carried the reduction's tail into both kernels and chose
 //                  with 64-bit selects was 9 % SLOWER than the library's; this one is 16 % faster (sky2pix 57 -> 66 %)
 //   pxl_fm_rsqrt   seed + one third-order step; <= 1 ulp
@@ -144,7 +144,24 @@ PXL_FM_HD double pxl_fm_atan2(double y, double x) {
     return (x != x || y != y) ? x + y : a;
 }
 
-// asin(v); NaN outside [-1, 1].  HALF (compile time): 0 = any v (both halves evaluated, one selected); 1 = the caller guarantees
+// w with a tiny negative value, w in [-2^-50, -0], replaced by (effectively) +0: one integer compare and one select on the high
+// word.  Positive values, larger negative ones and NaN pass unchanged.
+PXL_FM_HD double pxl_fm_lift_tiny_negative(double w) {
+    unsigned long long b;
+    __builtin_memcpy(&b, &w, 8);
+    const int hi = (int)(unsigned)(b >> 32);
+    // as a signed word: every non-negative double has hi >= 0; the negative ones run from INT_MIN (-0) upwards with their magnitude,
+    // and 0xBCD... is the high word of -2^-50
+    const unsigned hi2 = hi <= (int)0xBCD00000u ? 0u : (unsigned)hi;
+    b = ((unsigned long long)hi2 << 32) | (b & 0xFFFFFFFFull);          // the low word may stay: below 2^-1022 either way
+    __builtin_memcpy(&w, &b, 8);
+    return w;
+}
+
+// asin(v); NaN for |v| > 1 + 2^-49, and SATURATING at +-pi/2 for 1 < |v| <= 1 + 2^-49: the evaluators' argument is a quotient that is
+// at most 1 mathematically but is formed from three rounded factors (numerator, reciprocal square root, their product), so it
+// overshoots 1 by up to 4.4e-16 for pixels on a celestial pole (2.26 M of 20 M patch centres) -- those are the pole,
+// not an error.  HALF (compile time): 0 = any v (both halves evaluated, one selected); 1 = the caller guarantees
 // |v| <= 1/2, 2 = |v| > 1/2 or NaN (it has tested a whole wave): only that half is evaluated -- the same operations, the same bits.
 template <int HALF = 0>
 PXL_FM_HD double pxl_fm_asin(double v) {
@@ -156,7 +173,7 @@ PXL_FM_HD double pxl_fm_asin(double v) {
     }
     const bool big = HALF == 2 || av > 0.5;
     // big: asin(av) = pi/2 - 2 asin(sqrt(w)), w = (1 - av) / 2 (exact for av in (1/2, 1], and then in [2^-54, 1/4) or 0)
-    const double w = __builtin_fma(-0.5, av, 0.5);
+    const double w = pxl_fm_lift_tiny_negative(__builtin_fma(-0.5, av, 0.5));
     // sqrt(w) = b + blo: one Goldschmidt step from the seed, then two corrections by the exact residual w - s^2
     const double y0 = pxl_fm_rsq_seed(w + 0x1p-200);                       // w itself for w >= 2^-54; finite for w = 0 (|v| = 1)
     const double h = 0.5 * y0;
@@ -190,8 +207,13 @@ PXL_FM_HD double pxl_fm_flip_if_bit1(double v, int q) {
 // the library.  Cody-Waite reduction by pi/2 in two 53-bit parts -- the first step is exact (|n| < 2^20: the difference is a
 // multiple of 2^-53 below 1 in magnitude), the second is rounded once, which is the whole reduction error: 0.5 ulp of the reduced
 // argument (the third part of pi/2, n * 1e-33, is dropped) -- then the two kernels on |r| <= pi/4 and a quadrant step made of one
-// swap and two sign flips.  <= 1.5 ulp; about 40 instructions against the library's ~65 (half of those are its reduction's
-// double-double arithmetic and the selects of the quadrant logic).
+// swap and two sign flips.  Error bound: <= 1.5 ulp OF max(|sin|, |cos|), i.e. an ABSOLUTE 1.7e-16 -- not a relative bound on the
+// small component next to a multiple of pi/2: there the dropped third part of pi/2 (n * 1.5e-33) and the rounding of the second step
+// (2^-53 |n| pi/2 relative to a reduced argument that can be as small as 3e-16 at n ~ 5e5) leave an absolute error of ~1e-27 in a
+// value of ~3e-16, 1e-12 relative.  The evaluators multiply these sines and cosines into direction cosines of order 1,
+// so the absolute bound is the one that matters; tests/native/fastmath_check.cpp checks it at the worst-case arguments near
+// k pi/2 as an absolute bound.  About 40 instructions against the library's ~65 (half of those are its reduction's double-double
+// arithmetic and the selects of the quadrant logic).
 PXL_FM_HD bool pxl_fm_sincos(double x, double* sn, double* cs) {
     constexpr double S[PXL_FM_SIN_S_N] = PXL_FM_SIN_S;
     constexpr double Cc[PXL_FM_COS_C_N] = PXL_FM_COS_C;

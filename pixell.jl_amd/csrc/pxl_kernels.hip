@@ -298,12 +298,16 @@ int pxl_mem_probe_pair(void* a, void* b, size_t window_bytes, int reps, float* u
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    {
+        hipError_t ec = hipEventCreate(&e1);
+        if (ec != hipSuccess) { (void)hipEventDestroy(e0); return fail(PXL_EHIP, "hipEventCreate(&e1): %s", hipGetErrorString(ec)); }
+    }
     std::vector<float> t(reps);
     int rc = PXL_OK;
     for (int r = -1; r < reps && rc == PXL_OK; ++r) {
         hipError_t e = hipEventRecord(e0, st);
         hipLaunchKernelGGL(k_spread_probe, dim3(8 * 256 * 2), dim3(256), 0, st, (char*)a, (char*)b, window_bytes / 4);
+        if (e == hipSuccess) e = hipGetLastError();          // a refused launch would otherwise time an empty interval
         if (e == hipSuccess) e = hipEventRecord(e1, st);
         if (e == hipSuccess) e = hipEventSynchronize(e1);
         float ms = 0.f;
@@ -489,7 +493,8 @@ int pxl_posmap_car_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64_t r
     const int64_t nych = (nrows + PXL_POS_ROWS - 1) / PXL_POS_ROWS;
     int fronts = env_int("PXL_POSMAP_FRONTS", 8);
     if (fronts < 1 || nych < 16 * fronts) fronts = 1;
-    const int64_t per = (nych + fronts - 1) / fronts;
+    int64_t per = (nych + fronts - 1) / fronts;
+    if (per * fronts > 65535) { fronts = 1; per = nych; }      // rounding up to a multiple of `fronts` must not pass the grid.y limit
     dim3 grid((unsigned)(((shape[0] + 1) / 2 + 255) / 256), (unsigned)(per * fronts));
     hipLaunchKernelGGL(k_posmap_car, grid, dim3(256), 0, (hipStream_t)stream,
                        car_affine(*wcs), shape[0], row0, nrows, ra, dec, safe ? 1 : 0, fronts);

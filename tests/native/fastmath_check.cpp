@@ -75,6 +75,21 @@ int main(int argc, char** argv) {
         e_sin_big = std::max(e_sin_big, err_ulp(sn, sinl((long double)xl)));
         e_cos_big = std::max(e_cos_big, err_ulp(cs, cosl((long double)xl)));
     }
+    // the worst arguments for the two-part reduction: the doubles nearest to k pi/2 (and their neighbours), every k up to the limit
+    // of the fast path.  The small component there is ~1e-16..1e-11 and only an ABSOLUTE bound holds for it (pxl_fastmath.h).
+    double e_near_abs = 0, w_near = 0;
+    {
+        const long double pio2l = 1.57079632679489661923132169163975144L;
+        for (long k = 1; k <= 524287; ++k) {
+            const double xc = (double)(k * pio2l);
+            for (double xs : {xc, std::nextafter(xc, 0.0), std::nextafter(xc, 1e9), -xc}) {
+                double sn, cs;
+                if (!pxl_fm_sincos(xs, &sn, &cs)) { printf("{\"error\": \"fast path refused %g\"}\n", xs); return 1; }
+                const double ea = (double)std::max(fabsl((long double)sn - sinl((long double)xs)), fabsl((long double)cs - cosl((long double)xs)));
+                if (ea > e_near_abs) { e_near_abs = ea; w_near = xs; }
+            }
+        }
+    }
     // special cases: bit-for-bit what libm returns
     const double inf = INFINITY, nan = NAN;
     const double sp[] = {0.0, -0.0, 1.0, -1.0, inf, -inf, nan, 5e-324, -5e-324, 1e308, -1e308, 0.5, 0.75, 2.0};
@@ -86,7 +101,16 @@ int main(int argc, char** argv) {
                 if (!(std::isnan(g) && std::isnan(w))) { ++special_bad; fprintf(stderr, "atan2(%g, %g) = %a, libm %a\n", y, x, g, w); }
             }
         }
-    for (double v : {0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 1.0000000000000002, -1.5, (double)inf, (double)nan, 5e-324, 1e-200}) {
+    // saturation band: 1 < |v| <= 1 + 2^-49 is the pole (a rounded quotient of at most 1), beyond it NaN as in libm
+    for (double v : {1.0000000000000002, -1.0000000000000002, 1.0000000000000004, 1.0 + 0x1p-49, -(1.0 + 0x1p-49)}) {
+        const double want = std::copysign(std::asin(1.0), v);
+        for (double g : {pxl_fm_asin(v), pxl_fm_asin<2>(v)})
+            if (!same_bits(g, want)) { ++special_bad; fprintf(stderr, "asin(%a) = %a, expected the pole %a\n", v, g, want); }
+    }
+    for (double v : {1.0 + 0x1p-48, -(1.0 + 0x1p-48), 1.00000001, -1.00000001, 2.0})
+        for (double g : {pxl_fm_asin(v), pxl_fm_asin<2>(v)})
+            if (!std::isnan(g)) { ++special_bad; fprintf(stderr, "asin(%a) = %a, expected NaN\n", v, g); }
+    for (double v : {0.0, -0.0, 1.0, -1.0, 0.5, -0.5, -1.5, (double)inf, (double)nan, 5e-324, 1e-200}) {
         double g = pxl_fm_asin(v), w = std::asin(v);
         if (!(same_bits(g, w) || err_ulp(g, asinl((long double)v)) <= 1.0) || (!std::isnan(w) && std::signbit(g) != std::signbit(w))) { ++special_bad; fprintf(stderr, "asin(%g) = %a, libm %a\n", v, g, w); }
     }
@@ -106,7 +130,7 @@ int main(int argc, char** argv) {
     if (!(std::isnan(pxl_fm_rsqrt(inf)) && std::isnan(pxl_fm_rsqrt(nan)) && pxl_fm_rsqrt(4.0) == 0.5)) ++special_bad;
     printf("{\"samples\": %ld, \"atan2_max_ulp\": %.3f, \"atan2_worst\": [%.17g, %.17g], \"asin_max_ulp\": %.3f, \"asin_worst\": %.17g, "
            "\"sin_max_ulp\": %.3f, \"sin_worst\": %.17g, \"cos_max_ulp\": %.3f, \"cos_worst\": %.17g, \"sin_max_ulp_big\": %.3f, \"cos_max_ulp_big\": %.3f, \"rsqrt_max_ulp\": %.3f, "
-           "\"rsqrt_worst\": %.17g, \"tame_samples\": %ld, \"tame_bad\": %ld, \"asin_half_bad\": %ld, \"special_bad\": %d}\n",
-           n, e_atan2, w_atan2[0], w_atan2[1], e_asin, w_asin, e_sin, w_sin, e_cos, w_cos, e_sin_big, e_cos_big, e_rsqrt, w_rsqrt, n_tame, tame_bad, half_bad, special_bad);
+           "\"rsqrt_worst\": %.17g, \"tame_samples\": %ld, \"tame_bad\": %ld, \"asin_half_bad\": %ld, \"special_bad\": %d, \"sincos_near_kpio2_max_abs\": %.4g, \"sincos_near_kpio2_worst\": %.17g}\n",
+           n, e_atan2, w_atan2[0], w_atan2[1], e_asin, w_asin, e_sin, w_sin, e_cos, w_cos, e_sin_big, e_cos_big, e_rsqrt, w_rsqrt, n_tame, tame_bad, half_bad, special_bad, e_near_abs, w_near);
     return 0;
 }

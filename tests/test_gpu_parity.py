@@ -947,6 +947,99 @@ def test_gnomonic_wide_fields_on_device(pj, O, dev):
         assert np.abs(x.cpu().numpy() - ex).max() < 1e-6 and np.abs(y.cpu().numpy() - ey).max() < 1e-6
 
 
+def test_gnomonic_celestial_pole_is_finite_on_device(pj, O, dev):
+    """the sine handed to asin is a product of three rounded factors and overshoots 1 by up to 4.4e-16 for a
+    pixel ON a celestial pole (one patch centre in nine); pxl_fm_asin saturates that band to +-pi/2 instead of returning NaN.
+    (1) sky2pix(ra, +-pi/2) -> pix2sky for many patch centres must give +-pi/2 back; (2) a posmap whose grid contains the pole
+    pixel is finite, with the pole's declination at that pixel."""
+    rng = np.random.default_rng(88)
+    d0s = np.concatenate([rng.uniform(5.0, 89.999, 160), rng.uniform(-89.999, -5.0, 160), [90.0, -90.0, 89.99999, 45.0, 30.0, 60.0]])
+    ras = to_dev(rng.uniform(-np.pi, np.pi, 64), dev)
+    worst = 0.0
+    for d0 in d0s:
+        wcs = pj.Gnomonic((-1.0 / 60, 1.0 / 60), (1000.5, 900.5), (float(rng.uniform(-180, 180)), float(d0)))
+        pole = math.copysign(math.pi / 2, d0)                 # the pole in front of this tangent plane
+        x, y = pj.sky2pix(((2000, 1800), wcs), ras, torch.full_like(ras, pole), safe=False)
+        ra, dec = pj.pix2sky(((2000, 1800), wcs), x, y, safe=False)
+        dec = dec.cpu().numpy()
+        assert np.isfinite(dec).all(), (d0, dec)
+        assert np.isfinite(ra.cpu().numpy()).all(), d0
+        worst = max(worst, np.abs(dec - pole).max())
+    # asin near 1 has square-root conditioning: |ddec| <= sqrt(2 eps k) for a sine that is k ulp off
+    assert worst < 1e-7, worst
+    for d0, res_arcmin in ((88.0, 1.0), (-89.5, 0.5), (75.0, 4.0)):
+        wcs0 = pj.Gnomonic((-res_arcmin / 60, res_arcmin / 60), (256.5, 256.5), (33.0, d0))
+        pole = math.copysign(math.pi / 2, d0)
+        xp, yp = O.sky2pix_tan(wcs0, np.array([0.0]), np.array([pole]))
+        # move the reference pixel so that the pole lands exactly on a pixel centre inside the grid
+        wcs = pj.Gnomonic(wcs0.cdelt, (256.5 + (round(xp[0]) - xp[0]), 256.5 + (round(yp[0]) - yp[0])), (33.0, d0))
+        ip, jp = int(round(xp[0])), int(round(yp[0]))
+        shape = (max(512, ip + 8), max(512, jp + 8))
+        assert 1 <= ip <= shape[0] and 1 <= jp <= shape[1], (ip, jp)
+        ra, dec = pj.posmap(shape, wcs, device=dev)
+        ra, dec = ra.data.cpu().numpy(), dec.data.cpu().numpy()
+        assert np.isfinite(ra).all() and np.isfinite(dec).all(), d0
+        assert abs(dec[jp - 1, ip - 1] - pole) < 1e-7, (d0, dec[jp - 1, ip - 1])
+        jj, ii = np.meshgrid(np.arange(1, shape[1] + 1, dtype=float), np.arange(1, shape[0] + 1, dtype=float), indexing="ij")
+        era, edec = O.pix2sky_tan(wcs, ii.ravel(), jj.ravel())
+        ok = np.isfinite(edec)
+        assert np.abs(dec.ravel()[ok] - edec[ok]).max() < 1e-7
+
+
+def _tan_pix2sky_longdouble(wcs, ii, jj):
+    """tan_proj.jl:59-75 operation for operation in numpy long double (x87 80-bit here): the yardstick for the polar-patch test."""
+    L = np.longdouble
+    pi = L("3.14159265358979323846264338327950288")
+    unit, scale = L(wcs.unit), L(1.0) / L(wcs.cdelt[0])
+    a0, d0 = L(wcs.crval[0]) * (pi / 180), L(wcs.crval[1]) * (pi / 180)
+    X = (L(wcs.crpix[0]) - ii.astype(L)) * unit / scale
+    Y = (L(wcs.crpix[1]) - jj.astype(L)) * unit / scale
+    D = np.arctan(np.sqrt(X * X + Y * Y))
+    B = np.arctan2(-X, Y)
+    XX = np.sin(d0) * np.sin(D) * np.cos(B) + np.cos(d0) * np.cos(D)
+    YY = np.sin(D) * np.sin(B)
+    return a0 + np.arctan2(YY, XX), np.arcsin(np.sin(d0) * np.cos(D) - np.cos(d0) * np.sin(D) * np.cos(B))
+
+
+def test_gnomonic_polar_patch_posmap_l1_on_device(pj, O, dev):
+    """the reference's bar for its Gnomonic code is an L1 sum over a whole posmap, sum|diff| < 1e-9 for the
+    3 334 275 pixels of its 1827 x 1825 patch (test_geometry.jl:116-119), i.e. 3.0e-16 per pixel.  Evaluated here on POLAR patches
+    (centres at |dec| >= 88 degrees, the pole inside the grid), scaled by the pixel count.  At a pole that bar cannot hold for ANY
+    double-precision evaluation, the reference's own formula included: dec = asin(s) has d(dec)/ds = 1 / cos(dec) and RA is the
+    longitude of a point at distance cos(dec) from the axis, so one ulp of the intermediate direction cosine is eps / cos(dec) of
+    angle.  So the yardstick is the reference's formula in long double; measured against it
+      * the device's L1 error must not exceed the ORACLE's (glibc, the reference's operation order in double) by more than the
+        reference's bar, for DEC and for RA as a distance on the sky (dRA cos dec);
+      * the device must meet the reference's bar itself, unscaled, on the part of the patch farther than 1 degree from the pole."""
+    if np.finfo(np.longdouble).eps > 2e-19:
+        pytest.skip("long double is not wider than double here")
+    per_pixel = 1e-9 / (1827 * 1825)
+    for crval, res_arcmin, n in (((40.0, 88.39), 0.5, 1024), ((-120.0, -89.2), 1.0, 768), ((0.0, 90.0), 0.5, 512)):
+        wcs = pj.Gnomonic((-res_arcmin / 60, res_arcmin / 60), (n / 2 + 0.5, n / 2 + 0.5), crval)
+        ra, dec = pj.posmap((n, n), wcs, device=dev)
+        ra, dec = ra.data.cpu().numpy().ravel(), dec.data.cpu().numpy().ravel()
+        assert np.isfinite(ra).all() and np.isfinite(dec).all()
+        jj, ii = np.meshgrid(np.arange(1, n + 1, dtype=float), np.arange(1, n + 1, dtype=float), indexing="ij")
+        ii, jj = ii.ravel(), jj.ravel()
+        era, edec = O.pix2sky_tan(wcs, ii, jj)
+        tra, tdec = _tan_pix2sky_longdouble(wcs, ii, jj)
+        cosd = np.cos(tdec).astype(float)
+
+        def l1(a, d, sel=slice(None)):
+            dra = np.abs((a - tra).astype(float))
+            dra = np.minimum(dra, np.abs(dra - 2 * np.pi))    # atan2's branch cut passes through the pole
+            return (dra * cosd)[sel].sum(), np.abs((d - tdec).astype(float))[sel].sum()
+        bound = per_pixel * n * n
+        dev_ra, dev_dec = l1(ra, dec)
+        ora_ra, ora_dec = l1(era, edec)
+        far = cosd > math.sin(math.radians(1.0))
+        far_ra, far_dec = l1(ra, dec, far)
+        print("polar patch %s: device L1 ra*cos(dec) %.3e dec %.3e | oracle %.3e %.3e | bar %.3e | beyond 1 deg of the pole: %.3e %.3e (bar %.3e)"
+              % (crval, dev_ra, dev_dec, ora_ra, ora_dec, bound, far_ra, far_dec, per_pixel * far.sum()))
+        assert dev_ra < ora_ra + bound and dev_dec < ora_dec + bound, (crval, dev_ra, ora_ra, dev_dec, ora_dec, bound)
+        assert far_ra < per_pixel * far.sum() and far_dec < per_pixel * far.sum(), (crval, far_ra, far_dec)
+
+
 @pytest.mark.parametrize("f32", [False, True])
 def test_reproject_every_tile_shape(pj, O, dev, f32, monkeypatch):
     """The LDS-DMA kernel is instantiated per (storage type, lane width, 16-byte chunks per source-row segment):
