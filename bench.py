@@ -45,6 +45,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: required for RCCL P2P on this pool
+# Thread placement of the cpu_baseline legs: NOT bound.  OMP_PROC_BIND would have to be set before libgomp loads (at `import
+# torch`) and then pins this process's main thread to one CPU -- a mask that every child (the self-launched ranks, the rocprofv3
+# passes) inherits.  The legs report the variables as they are (normally unset: threads float under the Linux scheduler).
 
 import torch                      # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -109,36 +112,103 @@ def fill_strip(sh, src, seed):
         pj.fill_random_(plane, seed + c, offset=own_lo * nx, kind="normal")
 
 
-def cpu_baseline_reproject(shape_in, wcs_in, shape_out, wcs_out, budget_s=12.0):
+def host_cpu_share():
+    """What this process may really use of the host: hardware threads, physical cores, the affinity mask and the cgroup CPU quota
+    (a GPU box hands a one-GPU job a share of a 128-thread host; 128 OpenMP threads inside a 16-CPU quota is how round 3 got a 7x
+    'all-core' speed-up).  threads = min of the three, and that is what the all-core legs run with."""
+    hw = os.cpu_count() or 1
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = hw
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2
+            q, per = f.read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:      # cgroup v1
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = float(f.read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    model, cores = None, set()
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and model is None:
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+    except Exception:
+        pass
+    threads = max(1, min(hw, aff, int(math.ceil(quota)) if quota else hw))
+    return {"threads": threads, "hardware_threads": hw, "physical_cores": len(cores) or None, "affinity_cpus": aff,
+            "cgroup_cpu_quota": None if quota is None else round(quota, 2), "cpu_model": model,
+            "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES")}
+
+
+def _cpu_median_rate(run, units, threads, runs=5):
+    """median of >= 5 runs.  `run()` executes the oracle loop once into a caller-allocated output; the FIRST call
+    is untimed -- it faults the output pages in (first touch by the threads that will write them: static OpenMP schedule, so every
+    timed run finds its pages where its threads are) and warms the instruction cache.  Returns (units / s at the median, times)."""
+    from oracle import oracle as O
+    O.set_threads(threads)
+    try:
+        run()
+        times = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            run()
+            times.append(time.perf_counter() - t0)
+    finally:
+        O.set_threads(1)
+    times.sort()
+    return units / times[len(times) // 2], [round(t, 4) for t in times]
+
+
+def cpu_baseline_reproject(shape_in, wcs_in, shape_out, wcs_out):
     """Time the CPU oracle (a C port of the reference arithmetic; the reference has no reprojection of its
-    own and Julia is not installed) on a bounded strip of the same workload."""
+    own and Julia is not installed) on a bounded strip of the same workload: one core (the reference's execution model) and
+    every CPU this process may use, median of 5 runs each, output allocated and touched before the first timed run."""
     import numpy as np
     from oracle import oracle as O
     nx, ny, nc = shape_in
     nxo, nyo = shape_out
     mid = nyo // 2
+    host = host_cpu_share()
+    cores = max(1, min(O.max_threads(), host["threads"]))
 
-    def run(nrows, threads):
+    def leg(nrows, threads):
         lo = mid - nrows // 2
         s_lo, s_hi = O.reproject_src_rows(wcs_in, shape_in, wcs_out, shape_out, lo, nrows)
-        rng = np.random.default_rng(1234)
-        src = rng.random((nc, s_hi - s_lo, nx))
-        O.set_threads(threads)
-        t0 = time.perf_counter()
-        O.reproject(wcs_in, shape_in, src, wcs_out, shape_out, src_row0=s_lo, src_nrows=s_hi - s_lo, dst_row0=lo,
-                    dst_nrows=nrows)
-        dt = time.perf_counter() - t0
-        O.set_threads(1)
-        return nxo * nrows * nc / dt / 1e6
+        src = np.random.default_rng(1234).random((nc, s_hi - s_lo, nx))
+        out = np.empty((nc, nrows, nxo))
+        rate, times = _cpu_median_rate(lambda: O.reproject(wcs_in, shape_in, src, wcs_out, shape_out, src_row0=s_lo, src_nrows=s_hi - s_lo,
+                                                           dst_row0=lo, dst_nrows=nrows, out=out), nxo * nrows * nc, threads)
+        return rate / 1e6, times
 
-    rows1 = min(max(8, int(1.5e9 / (nxo * nc))), nyo // 2)  # ~1.5e9 output values (~10 s) for the 1-core leg
-    v1 = run(rows1, 1)
-    cores = min(O.max_threads(), os.cpu_count() or 1)
-    rowsN = max(rows1, int(min(budget_s * v1 * 1e6 * cores * 0.5, 1.5e9) / (nxo * nc)))
-    rowsN = max(min(rowsN, nyo // 2), rows1)
-    vN = run(rowsN, cores)
+    # ~1 s per run: ~1.5e8 output values on one core (150 Mpix/s in round 3), scaled by a short calibration leg for all cores
+    rows1 = min(max(8, int(1.5e8 / (nxo * nc))), nyo // 2)
+    v1, t1 = leg(rows1, 1)
+    vcal, _ = leg(rows1, cores) if cores > 1 else (v1, None)
+    rowsN = max(rows1, min(int(1.0 * vcal * 1e6 / (nxo * nc)), nyo // 2, int(6e9 / (8 * nxo * nc))))
+    vN, tN = leg(rowsN, cores) if cores > 1 else (v1, t1)
     return {"value": round(vN, 1), "unit": "Mpix/s", "cores": cores, "kind": "port",
-            "value_1core": round(v1, 1),
+            "value_1core": round(v1, 1), "scaling_1_to_N": round(vN / v1, 2), "runs": 5, "statistic": "median of 5 timed runs after one untimed run",
+            "times_s": tN, "times_s_1core": t1, "host": host,
             "sample": "oracle/pixell_oracle.c reproject of %d (all-core) / %d (1-core) centre output rows x %d "
                       "columns x %d components of the same workload" % (rowsN, rows1, nxo, nc)}
 
@@ -363,6 +433,15 @@ def main():
             result["roofline"]["traffic_source"] = (result["roofline"].get("traffic_source") or "") + "; live measurement failed: %s" % detail
     if world == 1 and args.workload == "cfg4" and not args.no_configs:
         side_measurements(args, dev, result)
+    if world > 1 and args.workload == "cfg4" and not args.no_configs:
+        # the other multi-GPU BASELINE config in the same line, after the headline and outside its timed region: cfg5 -- the map
+        # replicated on every rank, the 1e9 points split evenly (pj.strip_bounds; rank r generates points [lo, hi) of the one seeded
+        # sequence), no data-path collective; same barrier + max-over-ranks timing, every rank's points oracle-checked
+        a = argparse.Namespace(**vars(args))
+        a.workload, a.steps, a.warmup = "cfg5", 6, 2
+        torch.cuda.empty_cache()
+        r = bench_scattered(a, rank, world, dev)
+        result.setdefault("configs", {})["cfg5"] = scattered_record(r, a.steps)
     if rank == 0:
         json_out.write(json.dumps(result) + "\n")
         json_out.flush()
@@ -596,13 +675,7 @@ def bench_reproject(args, rank, world, dev):
     if True:
         # the output of the LAST timed step is verified (outside the timed region): every rank checks rows of its own
         # strip (row 0 of a strip is the one that needs the halo) against the oracle; the worst case is reported
-        chk = spot_check(sh, src, dst, shape_in, wcs_in, shape_out, wcs_out)
-        if world > 1:
-            t = torch.tensor([chk["max_abs_err"], 0.0 if chk["bit_identical"] else 1.0], dtype=torch.float64,
-                             device="cpu" if _on_host() else dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_CTRL)
-            chk = {"max_abs_err": float(t[0]), "bit_identical": bool(t[1] == 0.0), "ranks_checked": world}
-        result["check"] = chk
+        result["check"] = reduce_check(spot_check(sh, src, dst, shape_in, wcs_in, shape_out, wcs_out), world, dev)
     if own_comm is not None:
         torch.cuda.synchronize(dev)
         sh.close_own_comm()
@@ -644,6 +717,30 @@ def spot_check(sh, src, dst, shape_in, wcs_in, shape_out, wcs_out, nrows=6):
         worst = max(worst, float(np.abs(got - exp).max()))
         bit_identical &= bool(np.array_equal(got.view(np.int64), exp.view(np.int64)))
     return {"max_abs_err": worst, "bit_identical": bit_identical}
+
+
+def reduce_check(chk, world, dev):
+    """Every rank checks its own strip / its own points against the oracle; the job reports the WORST case: the largest error
+    of any rank, bit-identical only if every rank was, and how many ranks took part (MAX over the job's ranks, on the host when
+    the control plane is gloo)."""
+    if world == 1:
+        return chk
+    where = "cpu" if _on_host() else dev
+    t = torch.tensor([chk["max_abs_err"], 0.0 if chk["bit_identical"] else 1.0], dtype=torch.float64, device=where)
+    cnt = torch.ones(1, dtype=torch.float64, device=where)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_CTRL)
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=_CTRL)
+    out = dict(chk)
+    out.update({"max_abs_err": float(t[0]), "bit_identical": bool(t[1] == 0.0), "ranks_checked": int(round(float(cnt[0])))})
+    return out
+
+
+def scattered_record(r, steps):
+    """The compact `configs.cfg5` record of a bench_scattered result."""
+    return {"workload": r["config"]["workload"], "parallelism": r["config"]["parallelism"], "Mpts_s": r["value"], "ms_per_step": r["ms_per_step"],
+            "n_gpus": r["n_gpus"], "scaling": r["scaling"], "kernel": r["roofline"]["kernel"], "kernel_ms_avg": r["roofline"]["kernel_ms_avg"],
+            "frac": r["roofline"]["frac"], "traffic": r["roofline"].get("traffic"), "steps": steps, "sampler": r["config"]["sampler"],
+            "check": r["check"], "variants": r.get("variants")}
 
 
 def bench_scattered(args, rank, world, dev):
@@ -747,12 +844,7 @@ def scattered_check(m, wcs, shape, sky, out, world, dev, npick=4096):
     exp = O.sample_bilinear(wcs, (shape[0], shape[1], 1), m.data.cpu().numpy()[None], pts)[0]
     chk = {"points_checked": int(idx.numel()), "max_abs_err": float(np.abs(got - exp).max()),
            "bit_identical": bool(np.array_equal(got.view(np.int64), exp.view(np.int64)))}
-    if world > 1:
-        t = torch.tensor([chk["max_abs_err"], 0.0 if chk["bit_identical"] else 1.0], dtype=torch.float64,
-                         device="cpu" if _on_host() else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_CTRL)
-        chk.update({"max_abs_err": float(t[0]), "bit_identical": bool(t[1] == 0.0), "ranks_checked": world})
-    return chk
+    return reduce_check(chk, world, dev)
 
 
 def side_measurements(args, dev, result):
@@ -787,9 +879,7 @@ def side_measurements(args, dev, result):
     a.workload, a.steps, a.warmup = "cfg5", 6, 2
     torch.cuda.empty_cache()
     r = bench_scattered(a, 0, 1, dev)
-    cfgs["cfg5"] = {"workload": r["config"]["workload"], "Mpts_s": r["value"], "ms_per_step": r["ms_per_step"],
-                    "kernel": r["roofline"]["kernel"], "kernel_ms_avg": r["roofline"]["kernel_ms_avg"], "frac": r["roofline"]["frac"],
-                    "steps": a.steps, "sampler": r["config"]["sampler"], "check": r["check"], "variants": r.get("variants")}
+    cfgs["cfg5"] = scattered_record(r, a.steps)
     torch.cuda.empty_cache()
     result["configs"] = cfgs
     result["evaluators"] = gpu_evaluators(dev)
@@ -896,39 +986,42 @@ def gpu_evaluators(dev):
 def cpu_baseline_evaluators():
     """The oracle's loops for the functions the reference DOES have (posmap: enmap_ops.jl:190-203; pix2sky! / sky2pix! on
     2xN: car_proj.jl:92-122, 165-200, safe=true as the reference defaults), on bounded samples of the 0.5-arcmin geometry:
-    one core (the reference's execution model) and all host cores (OpenMP)."""
+    one core (the reference's execution model) and every CPU this process may use (OpenMP), median of 5 runs each into
+    outputs that exist and have been touched before the first timed run."""
     import numpy as np
     from oracle import oracle as O
     shape, wcs = pj.fullsky_geometry(2 * math.pi / 43200)
     nx, ny = shape
-    cores = min(O.max_threads(), os.cpu_count() or 1)
+    host = host_cpu_share()
+    cores = max(1, min(O.max_threads(), host["threads"]))
     res = {}
 
-    def timed(fn, threads):
-        O.set_threads(threads)
-        t0 = time.perf_counter()
-        fn()
-        dt = time.perf_counter() - t0
-        O.set_threads(1)
-        return dt
-    rows1 = 600
-    v1 = nx * rows1 / timed(lambda: O.posmap(wcs, shape, row0=ny // 2 - rows1 // 2, nrows=rows1), 1) / 1e6
-    rowsN = int(min(8000, max(rows1, 2.0 * v1 * 1e6 * cores * 0.5 / nx)))
-    vN = nx * rowsN / timed(lambda: O.posmap(wcs, shape, row0=ny // 2 - rowsN // 2, nrows=rowsN), cores) / 1e6
-    res["posmap"] = {"value": round(vN, 1), "value_1core": round(v1, 1), "unit": "Mpix/s", "cores": cores, "kind": "port",
+    def posmap_leg(nrows, threads):
+        out = (np.empty((nrows, nx)), np.empty((nrows, nx)))
+        rate, times = _cpu_median_rate(lambda: O.posmap(wcs, shape, row0=ny // 2 - nrows // 2, nrows=nrows, out=out), nx * nrows, threads)
+        return rate / 1e6, times
+    rows1 = 2400                                       # ~0.5 s on one core at ~200 Mpix/s
+    v1, t1 = posmap_leg(rows1, 1)
+    vcal, _ = posmap_leg(rows1, cores) if cores > 1 else (v1, None)
+    rowsN = int(max(rows1, min(0.7 * vcal * 1e6 / nx, 8000)))
+    vN, tN = posmap_leg(rowsN, cores) if cores > 1 else (v1, t1)
+    res["posmap"] = {"value": round(vN, 1), "value_1core": round(v1, 1), "scaling_1_to_N": round(vN / v1, 2), "unit": "Mpix/s", "cores": cores,
+                     "kind": "port", "runs": 5, "times_s": tN, "times_s_1core": t1,
                      "sample": "oracle posmap (enmap_ops.jl:190-203, safe=true) of %d (all-core) / %d (1-core) centre rows x %d columns" % (rowsN, rows1, nx)}
     rng = np.random.default_rng(1)
-    n1 = 10_000_000
-    nN = int(min(200_000_000, max(n1, n1 * cores // 4)))
+    n1 = 20_000_000
+    nN = int(min(160_000_000, max(n1, n1 * cores // 8)))
     pix = rng.random((nN, 2)) * ny
     O.set_threads(cores)
     sky_pts = O.pix2sky(wcs, pix, O.WRAP_NONE)
     O.set_threads(1)
-    for name, arr, fn in (("pix2sky", pix, lambda a: O.pix2sky(wcs, a, O.WRAP_UNWIND)),
-                          ("sky2pix", sky_pts, lambda a: O.sky2pix(wcs, shape, a, safe=True))):
-        v1 = n1 / timed(lambda: fn(arr[:n1]), 1) / 1e6
-        vN = nN / timed(lambda: fn(arr), cores) / 1e6
-        res[name] = {"value": round(vN, 1), "value_1core": round(v1, 1), "unit": "Mpts/s", "cores": cores, "kind": "port",
+    out = np.empty_like(pix)
+    for name, arr, fn in (("pix2sky", pix, lambda a, o: O.pix2sky(wcs, a, O.WRAP_UNWIND, out=o)),
+                          ("sky2pix", sky_pts, lambda a, o: O.sky2pix(wcs, shape, a, safe=True, out=o))):
+        r1, t1 = _cpu_median_rate(lambda: fn(arr[:n1], out[:n1]), n1, 1)
+        rN, tN = _cpu_median_rate(lambda: fn(arr, out), nN, cores) if cores > 1 else (r1, t1)
+        res[name] = {"value": round(rN / 1e6, 1), "value_1core": round(r1 / 1e6, 1), "scaling_1_to_N": round(rN / r1, 2), "unit": "Mpts/s", "cores": cores,
+                     "kind": "port", "runs": 5, "times_s": tN, "times_s_1core": t1,
                      "sample": "oracle %s! on a 2xN batch (car_proj.jl:%s, safe=true) of %d (all-core) / %d (1-core) random points%s" % (
                          name, "92-122 + unwind!, enmap_ops.jl:26-32" if name == "pix2sky" else "165-200", nN, n1,
                          "; the unwrap recurrence is serial in the reference and stays serial here" if name == "pix2sky" else "")}

@@ -90,10 +90,12 @@ def unwind_row(a, period=2 * np.pi, ref=0.0):
     return a
 
 
-def pix2sky(wcs, pix, wrap_mode=WRAP_UNWIND):
-    """pix: (n, 2) array of (ra_pix, dec_pix) pairs == Julia 2xN column-major.  Returns (n, 2)."""
+def pix2sky(wcs, pix, wrap_mode=WRAP_UNWIND, out=None):
+    """pix: (n, 2) array of (ra_pix, dec_pix) pairs == Julia 2xN column-major.  Returns (n, 2).
+    out: a caller-allocated (n, 2) result array (bench.py's cpu_baseline touches it before timing)."""
     pix = _f64(pix)
-    sky = np.empty_like(pix)
+    sky = np.empty_like(pix) if out is None else out
+    assert sky.shape == pix.shape and sky.dtype == np.float64 and sky.flags.c_contiguous
     rc = lib().pxl_pix2sky_car_f64_cpu(C.byref(_w(wcs)), C.c_int64(pix.shape[0]), _dp(pix), _dp(sky),
                                        C.c_int(wrap_mode))
     assert rc == 0
@@ -109,9 +111,10 @@ def pix2sky_soa(wcs, ipix, jpix, safe=True):
     return ra, dec
 
 
-def sky2pix(wcs, shape, sky, safe=True, form=FORM_RECIP):
+def sky2pix(wcs, shape, sky, safe=True, form=FORM_RECIP, out=None):
     sky = _f64(sky)
-    pix = np.empty_like(sky)
+    pix = np.empty_like(sky) if out is None else out
+    assert pix.shape == sky.shape and pix.dtype == np.float64 and pix.flags.c_contiguous
     rc = lib().pxl_sky2pix_car_f64_cpu(C.byref(_w(wcs)), _i64(shape[:2]), C.c_int64(sky.shape[0]), _dp(sky),
                                        _dp(pix), C.c_int(bool(safe)), C.c_int(form))
     assert rc == 0
@@ -127,11 +130,15 @@ def sky2pix_soa(wcs, shape, ra, dec, safe=True, form=FORM_RECIP_AV):
     return x, y
 
 
-def posmap(wcs, shape, row0=0, nrows=None, safe=True):
-    """Returns (ra, dec) arrays of shape (nrows, nx) (C order == Julia (nx, nrows) column-major)."""
+def posmap(wcs, shape, row0=0, nrows=None, safe=True, out=None):
+    """Returns (ra, dec) arrays of shape (nrows, nx) (C order == Julia (nx, nrows) column-major).  out: caller-allocated (ra, dec)."""
     nx, ny = int(shape[0]), int(shape[1])
     nrows = ny - row0 if nrows is None else nrows
-    ra = np.empty((nrows, nx)); dec = np.empty((nrows, nx))
+    if out is None:
+        ra = np.empty((nrows, nx)); dec = np.empty((nrows, nx))
+    else:
+        ra, dec = out
+        assert ra.shape == (nrows, nx) and dec.shape == (nrows, nx) and ra.flags.c_contiguous and dec.flags.c_contiguous
     rc = lib().pxl_posmap_car_f64_cpu(C.byref(_w(wcs)), _i64((nx, ny)), C.c_int64(row0), C.c_int64(nrows),
                                       _dp(ra), _dp(dec), C.c_int(bool(safe)))
     assert rc == 0
@@ -221,15 +228,16 @@ def reproject_tables(wcs_in, shape_in, wcs_out, shape_out):
 
 
 def reproject(wcs_in, shape_in, src, wcs_out, shape_out, src_row0=0, src_nrows=None, dst_row0=0,
-              dst_nrows=None):
-    """src: (nc, src_nrows, nx) C-order.  Returns dst (nc, dst_nrows, nx_out)."""
+              dst_nrows=None, out=None):
+    """src: (nc, src_nrows, nx) C-order.  Returns dst (nc, dst_nrows, nx_out); out: a caller-allocated dst."""
     nx, ny, nc = _shape3(shape_in)
     nxo, nyo = int(shape_out[0]), int(shape_out[1])
     src = _f64(src)
     src_nrows = ny - src_row0 if src_nrows is None else src_nrows
     dst_nrows = nyo - dst_row0 if dst_nrows is None else dst_nrows
     assert src.size == nx * src_nrows * nc
-    dst = np.empty((nc, dst_nrows, nxo))
+    dst = np.empty((nc, dst_nrows, nxo)) if out is None else out
+    assert dst.shape == (nc, dst_nrows, nxo) and dst.dtype == np.float64 and dst.flags.c_contiguous
     rc = lib().pxl_reproject_car_bilinear_f64_cpu(
         C.byref(_w(wcs_in)), _i64((nx, ny, nc)), _dp(src), C.c_int64(src_row0), C.c_int64(src_nrows),
         C.byref(_w(wcs_out)), _i64((nxo, nyo)), _dp(dst), C.c_int64(dst_row0), C.c_int64(dst_nrows))

@@ -216,9 +216,23 @@ class DecStripReprojector(DecStripLayout):
         return src, dst, arena
 
     def rccl_comm_ptr(self):
-        """The ncclComm_t of this job's RCCL process group, for the native step (ProcessGroupNCCL._comm_ptr)."""
+        """The ncclComm_t of this job's RCCL process group, for the native step.  `ProcessGroupNCCL._comm_ptr` is a PRIVATE torch
+        API (present in torch 2.4 ... 2.10, this image's); it is looked up by name, and a torch without it raises a RuntimeError
+        that says which transport the caller takes instead -- `native_ready()` turns that into (False, reason) on every rank before
+        anything is posted, and bench.py / a host then uses a communicator made through the library's own ABI (`make_own_comm`:
+        pxl_comm_unique_id + pxl_comm_init_rank, no torch internals), or torch.distributed P2P (`step`)."""
         pg = self.group if self.group is not None else dist.distributed_c10d._get_default_group()
-        return int(pg._get_backend(self.device)._comm_ptr())
+        get_backend = getattr(pg, "_get_backend", None)
+        if get_backend is None:
+            raise RuntimeError("torch %s: ProcessGroup has no _get_backend(); use make_own_comm() (the library's own RCCL communicator) "
+                               "or step() (torch P2P) instead of torch's communicator" % torch.__version__)
+        backend = get_backend(self.device)
+        comm_ptr = getattr(backend, "_comm_ptr", None)
+        if comm_ptr is None:
+            raise RuntimeError("torch %s: %s has no _comm_ptr() (a private API; not an RCCL group, or removed in this version); use "
+                               "make_own_comm() (the library's own RCCL communicator) or step() (torch P2P) instead"
+                               % (torch.__version__, type(backend).__name__))
+        return int(comm_ptr())
 
     def make_own_comm(self, ctrl_group=None):
         """A communicator made through the library's own ABI (pxl_comm_unique_id / pxl_comm_init_rank) -- what a Julia

@@ -35,6 +35,39 @@ def test_bench_self_launch_two_ranks():
     assert "gloo" in d["config"]["parallelism"]
 
 
+def _two_rank_rehearsal(workload, extra_env):
+    env = dict(os.environ, PXL_BENCH_SHARE_GPU="1", **extra_env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--backend", "gloo", "--workload", workload], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_self_launch_two_ranks_cfg5():
+    """BASELINE config 5 with two ranks: the map replicated on both, the points split by pj.strip_bounds (rank r
+    generates points [lo, hi) of the one seeded sequence), no data-path collective, every rank's points checked against the oracle
+    and the checks reduced.  Rehearsal: both ranks share this GPU, control plane on gloo."""
+    d = _two_rank_rehearsal("cfg5", {"PXL_BENCH_POINTS": "2e6"})
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["unit"] == "Mpts/s"
+    assert "points sharded x2" in d["config"]["parallelism"] and "no collective" in d["config"]["parallelism"]
+    assert d["check"]["bit_identical"] and d["check"]["ranks_checked"] == 2 and d["check"]["points_checked"] > 0
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 56.0 * 1e6          # each rank's launch covers ITS million points
+
+
+def test_bench_two_ranks_line_carries_both_multi_gpu_configs():
+    """With N > 1 the default workload's line carries cfg4 (dec strips + halo) as the headline and, after it and outside its timed
+    region, configs.cfg5 (points sharded, map replicated) -- both multi-GPU BASELINE configs in one driver line."""
+    d = _two_rank_rehearsal("cfg4", {"PXL_BENCH_POINTS": "2e6"})
+    assert d["n_gpus"] == 2 and d["check"]["bit_identical"] and d["check"]["ranks_checked"] == 2
+    c5 = d["configs"]["cfg5"]
+    assert c5["n_gpus"] == 2 and c5["Mpts_s"] > 0 and "points sharded x2" in c5["parallelism"]
+    assert c5["check"]["bit_identical"] and c5["check"]["ranks_checked"] == 2
+
+
 @pytest.mark.parametrize("workload", ["cfg2", "cfg2:placed", "cfg5", "cfg5:pairs"])
 def test_bench_contract(workload):
     env = dict(os.environ, PXL_BENCH_POINTS="2e6")
