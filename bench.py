@@ -875,6 +875,7 @@ def side_measurements(args, dev, result):
                       "check": placed["check"], "class_aware_placement": placed, "plain_first_placement": plain}
         cfgs[name]["class_aware_placement"].pop("workload", None)
         cfgs[name]["class_aware_placement"].pop("bytes_per_output_value", None)
+        cfgs[name]["api_default"] = api_default_record(name, dev)
     a = argparse.Namespace(**vars(args))
     a.workload, a.steps, a.warmup = "cfg5", 6, 2
     torch.cuda.empty_cache()
@@ -886,6 +887,55 @@ def side_measurements(args, dev, result):
     torch.cuda.empty_cache()
     if "cpu_baseline" in result:
         result["cpu_baseline"].update(cpu_baseline_evaluators())
+
+
+def api_default_record(name, dev, steps=10, warmup=2):
+    """EXACTLY what a caller of the drop-in API gets: the source map in a plain torch allocation wrapped in an
+    Enmap, `out = pj.reproject(m, shape_out, wcs_out)` -- the library allocates the output by its default policy
+    (placement.empty_map: class-aware, no head-room kept) --, then the same call repeated with `out=` and `plan=` reused, HIP
+    events around each call (table build + reprojection, like a headline step).  Reports the kernel-level time per call, what
+    the first call cost (allocation search + plan + tables + launch), the memory held afterwards against the size of the pair,
+    and an oracle check of the output."""
+    import types
+    shape_in, wcs_in, shape_out, wcs_out, desc = workload_geometry(name)
+    nx, ny, nc = shape_in
+    nxo, nyo = shape_out
+    torch.cuda.empty_cache()
+    base_reserved = torch.cuda.memory_reserved(dev)
+    src = torch.empty((nc, ny, nx), dtype=torch.float64, device=dev)
+    for c in range(nc):
+        pj.fill_random_(src[c], 1234 + c)
+    m = pj.Enmap(src if nc > 1 else src[0], wcs_in)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    out = pj.reproject(m, shape_out, wcs_out)
+    torch.cuda.synchronize(dev)
+    first_s = time.perf_counter() - t0
+    held = torch.cuda.memory_reserved(dev) - base_reserved
+    pair = 8.0 * nc * (nx * ny + nxo * nyo)
+    plan = pj.ReprojectPlan(m.shape, m.wcs, shape_out, wcs_out, device=dev)
+    for _ in range(warmup):
+        pj.reproject(m, shape_out, wcs_out, out=out, plan=plan)
+    torch.cuda.synchronize(dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev:
+        a.record()
+        pj.reproject(m, shape_out, wcs_out, out=out, plan=plan)
+        b.record()
+    torch.cuda.synchronize(dev)
+    ms = sorted(a.elapsed_time(b) for a, b in ev)
+    avg = sum(ms) / len(ms)
+    dst3 = out.data if out.data.dim() == 3 else out.data[None]
+    chk = spot_check(types.SimpleNamespace(dst_window=(0, nyo), buf_lo=0), src, dst3, shape_in, wcs_in, shape_out, wcs_out)
+    rec = {"call": "pj.reproject(m, shape_out, wcs_out): output allocated by the library (policy %r), source in a plain torch.empty" % pj.allocation_policy(),
+           "ms_per_call": round(avg, 4), "ms_median": round(ms[len(ms) // 2], 4), "frac": round(pair / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "Mpix_s": round(nxo * nyo * nc / (avg * 1e-3) / 1e6, 1), "steps": steps,
+           "first_call_s": round(first_s, 3), "held_after_call_GiB": round(held / 2**30, 2), "pair_GiB": round(pair / 2**30, 2),
+           "held_over_pair": round(held / pair, 3), "check": chk}
+    plan.close()
+    del out, m, src, dst3
+    torch.cuda.empty_cache()
+    return rec
 
 
 def variant(a, dev):
@@ -1010,7 +1060,7 @@ def cpu_baseline_evaluators():
                      "sample": "oracle posmap (enmap_ops.jl:190-203, safe=true) of %d (all-core) / %d (1-core) centre rows x %d columns" % (rowsN, rows1, nx)}
     rng = np.random.default_rng(1)
     n1 = 20_000_000
-    nN = int(min(160_000_000, max(n1, n1 * cores // 8)))
+    nN = int(min(200_000_000, max(n1, n1 * cores // 2)))
     pix = rng.random((nN, 2)) * ny
     O.set_threads(cores)
     sky_pts = O.pix2sky(wcs, pix, O.WRAP_NONE)

@@ -1111,7 +1111,10 @@ int pxl_reproject_generic_bilinear_f64(const pxl_car_wcs* wcs_in, int proj_in, c
     double2* lat = (double2*)ws;
     int32_t* flag = (int32_t*)(ws + lat_bytes);
     hipLaunchKernelGGL(k_generic_lattice, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, p, gx, ntiles, lat, flag);
-    hipLaunchKernelGGL(k_reproject_generic_tiled, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, (const double2*)lat, (const int32_t*)flag);
+    if (env_int("PXL_GENERIC_V1", 0))       // round 3's pixel kernel (one pixel per lane, 8-byte taps and stores): kept for A/B
+        hipLaunchKernelGGL(k_reproject_generic_tiled, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, (const double2*)lat, (const int32_t*)flag);
+    else
+        hipLaunchKernelGGL(k_reproject_generic_tiled2, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, (const double2*)lat, (const int32_t*)flag);
     hipLaunchKernelGGL(k_reproject_generic_exact_tiles, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, (const int32_t*)flag);
     int rc = check_launch("k_reproject_generic_tiled");
     hipError_t fe = hipFreeAsync(ws, st);

@@ -366,3 +366,110 @@ def place_pair_native(src_shape, dst_shape, dtype=torch.float64, device="cuda", 
             "src_own_class": bool(pair.src_own_class), "probes": pair.probes, "separate_source_allocation": bool(pair.src_alloc),
             "separate_tried": pair.separate_tried}
     return src, dst, info
+
+
+# ---- the library's default allocation policy for map-sized outputs ---------------------------------------------------------
+#
+# What `pj.reproject(m, shape_out, wcs_out)` (no `out=`), `DecStripReprojector.alloc_pair()` and the Julia `reproject` / `similar`
+# allocate through.  "class-aware" (the default): a destination of 3 GiB or more is allocated on its own and its 1 GiB windows
+# are labelled with the store probe; a candidate that lies inside ONE memory class is kept as ballast while the next one is
+# tried (consecutive allocations walk through the device's memory: a class boundary is at most one class run away, 4-32 GiB on
+# the boxes seen), and all ballast goes back to the driver before the call returns -- afterwards exactly the map is allocated,
+# no head-room.  "plain": torch.empty, nothing probed.  PXL_ALLOC_POLICY / set_allocation_policy() choose; PXL_ALLOC_BUDGET_GIB
+# bounds the transient ballast (default 96, and never more than the free memory less 8 GiB).
+import os as _os
+
+_POLICY = _os.environ.get("PXL_ALLOC_POLICY", "class-aware")
+_LABELS = {}          # (device index, data_ptr, nbytes) -> (labels, num_device_free when they were measured)
+MIN_PLACED_BYTES = 3 * GiB
+
+
+def set_allocation_policy(policy: str):
+    """'class-aware' (default) or 'plain'; returns the previous policy."""
+    global _POLICY
+    if policy not in ("class-aware", "plain"):
+        raise ValueError("allocation policy must be 'class-aware' or 'plain'")
+    old, _POLICY = _POLICY, policy
+    return old
+
+
+def allocation_policy() -> str:
+    return _POLICY
+
+
+def _device_frees(dev):
+    try:
+        return int(torch.cuda.memory_stats(dev).get("num_device_free", 0))
+    except Exception:           # noqa: BLE001
+        return -1
+
+
+def _labels_of(t: torch.Tensor):
+    """Class labels of the 1 GiB windows of `t` (probed once per block: torch's caching allocator hands the same block out again
+    with the same address, and its physical pages stay put until the allocator returns memory to the driver -- the cache entry
+    is dropped as soon as the device's free counter has moved).  OVERWRITES the probed windows with zeros."""
+    dev = t.device
+    key = (dev.index, t.data_ptr(), t.numel() * t.element_size())
+    frees = _device_frees(dev)
+    hit = _LABELS.get(key)
+    if hit is not None and hit[1] == frees and frees >= 0:
+        return hit[0], 0
+    offs, labels, cinfo = map_classes(t, step_gib=1)
+    if len(_LABELS) > 64:
+        _LABELS.clear()
+    _LABELS[key] = (labels, frees)
+    return labels, cinfo.get("probes", 0)
+
+
+def empty_map(shape, dtype=torch.float64, device="cuda", policy=None, budget_gib=None, accept_share=0.4, min_share=0.2, max_tries=24):
+    """(tensor, info): an uninitialised device tensor of `shape` allocated by the library's policy (above).  Contents are
+    unspecified (probed windows hold zeros).  info says what was done: policy, tries, the share of the buffer's windows in its
+    second class, seconds spent, bytes of ballast held transiently."""
+    import math
+    import time
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    policy = policy or _POLICY
+    esz = torch.empty((), dtype=dtype).element_size()
+    n = math.prod(shape)
+    nbytes = n * esz
+    if policy == "plain" or nbytes < MIN_PLACED_BYTES:
+        return torch.empty(tuple(shape), dtype=dtype, device=dev), {"policy": "plain" if policy == "plain" else "class-aware: below %d GiB, plain allocation" % (MIN_PLACED_BYTES // GiB), "tries": 1}
+    t0 = time.perf_counter()
+    if budget_gib is None:
+        budget_gib = float(_os.environ.get("PXL_ALLOC_BUDGET_GIB", "96"))
+    ballast, shares = [], []
+    best = None                  # (share, tensor)
+    held = 0
+    probes = 0
+    with torch.cuda.device(dev):
+        while True:
+            cand = torch.empty(n, dtype=dtype, device=dev)
+            labels, p = _labels_of(cand)
+            probes += p
+            _major, share = _split_of(labels)
+            shares.append(round(share, 2))
+            if best is None or share > best[0]:
+                if best is not None:
+                    ballast.append(best[1])
+                best = (share, cand)
+            else:
+                ballast.append(cand)
+            cand = None
+            held = sum(b.numel() * esz for b in ballast)
+            free, _t = torch.cuda.mem_get_info(dev)
+            if best[0] >= accept_share or len(shares) >= max_tries or held + nbytes > budget_gib * GiB or free < nbytes + 8 * GiB:
+                break
+        chosen = best[1]
+        freed = bool(ballast)
+        peak = held
+        del ballast
+        best = None
+        if freed:
+            torch.cuda.empty_cache()         # the ballast goes back to the driver: only the map stays allocated
+    share = max(shares)
+    how = ("two classes (%.0f %% of its windows in the second)" % (100 * share)) if share >= min_share else "one class (no boundary within the budget)"
+    info = {"policy": "class-aware", "placement": how, "tries": len(shares), "candidates_minor_share": shares, "probes": probes,
+            "seconds": round(time.perf_counter() - t0, 3), "transient_ballast_GiB": round(peak / GiB, 1), "held_GiB": round(nbytes / GiB, 2)}
+    return chosen.view(tuple(shape)), info

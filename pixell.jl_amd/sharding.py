@@ -192,6 +192,19 @@ class DecStripReprojector(DecStripLayout):
     def alloc_dst(self):
         return torch.empty(self.dst_tensor_shape(), dtype=torch.float64, device=self.device)
 
+    def alloc_maps(self, dtype=torch.float64, policy=None):
+        """(src zero-filled, dst, info): this rank's resident source strip and its output strip, allocated by the library's policy
+        (placement.py: class-aware by default -- the destination in two memory classes, the source in another one when there is
+        one, nothing kept beyond the two maps; 'plain' = alloc_pair).  What a host that lets the library allocate gets."""
+        from . import placement
+        policy = policy or placement.allocation_policy()
+        if policy == "plain":
+            src, dst, arena = self.alloc_pair(dtype)
+            return src, dst, {"policy": "plain", "arena": arena}
+        src, dst, info = placement.place_pair_compact(self.src_tensor_shape(), self.dst_tensor_shape(), dtype=dtype, device=self.device)
+        info["policy"] = "class-aware"
+        return src, dst, info
+
     def alloc_pair(self, dtype=torch.float64):
         """Source and destination buffers carved out of ONE device allocation, destination above the source on a 2 MiB
         boundary.  Where the write stream lands physically moves the reprojection by up to 8 % (stores alone: 3.2 vs 3.7

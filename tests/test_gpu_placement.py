@@ -162,3 +162,64 @@ def test_native_pair_alloc_through_the_abi(pj, dev):
     assert lib.pxl_mem_pair_alloc(0, 1 << 20, 0, C.byref(bad), None) != 0
     assert lib.pxl_mem_pair_alloc(1 << 20, 1 << 20, 0, None, None) != 0
     assert lib.pxl_mem_pair_free(None) != 0
+
+
+def test_default_allocation_policy_keeps_no_headroom(pj, O, dev):
+    """pj.reproject(m, shape_out, wcs_out) without `out=` allocates its output through placement.empty_map: by default a
+    destination of 3 GiB or more is looked for across a boundary between two memory classes, the rejected candidates are held
+    only while the search runs, and afterwards exactly the map is allocated (no 144 GiB of head-room).
+    The policy never changes a bit of the result."""
+    torch.cuda.empty_cache()
+    assert pj.allocation_policy() == "class-aware"
+    base = torch.cuda.memory_reserved(dev)
+    shape = (2, 8192, 32768)                                   # 4 GiB
+    t, info = pj.empty_map(shape, device=dev, budget_gib=40)
+    assert tuple(t.shape) == shape and t.dtype == torch.float64 and t.is_contiguous() and t.data_ptr() % 256 == 0
+    assert info["policy"] == "class-aware" and info["tries"] >= 1 and len(info["candidates_minor_share"]) == info["tries"]
+    assert info["transient_ballast_GiB"] <= 40.0
+    held = torch.cuda.memory_reserved(dev) - base
+    assert held <= t.numel() * 8 * 1.10 + (64 << 20), (held, info)   # nothing but the map (torch rounds blocks to 2 MiB)
+    # the same block asked for again is not probed a second time (labels cached per block while the allocator has freed nothing)
+    ptr = t.data_ptr()
+    del t
+    t2, info2 = pj.empty_map(shape, device=dev, budget_gib=40)
+    if t2.data_ptr() == ptr and info2["tries"] == 1:
+        assert info2["probes"] == 0, info2
+    del t2
+    small, sinfo = pj.empty_map((1024, 1024), device=dev)
+    assert "plain" in sinfo["policy"] and tuple(small.shape) == (1024, 1024)
+    old = pj.set_allocation_policy("plain")
+    try:
+        t3, info3 = pj.empty_map(shape, device=dev)
+        assert info3["policy"] == "plain" and info3["tries"] == 1
+        del t3
+    finally:
+        pj.set_allocation_policy(old)
+    with pytest.raises(ValueError):
+        pj.set_allocation_policy("fastest")
+    # through the API: a 2x refinement whose output is 3.2 GiB, allocated by the library, against the oracle
+    shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 14400)
+    shape_out, wcs_out = pj.fullsky_geometry(2 * math.pi / 28800)
+    src = torch.empty((shape_in[1], shape_in[0]), dtype=torch.float64, device=dev)
+    pj.fill_random_(src, 77)
+    out = pj.reproject(pj.Enmap(src, wcs_in), shape_out, wcs_out)
+    assert tuple(out.data.shape) == (shape_out[1], shape_out[0])
+    for r in (0, 5000, shape_out[1] - 1):
+        s_lo, s_hi = O.reproject_src_rows(wcs_in, (shape_in[0], shape_in[1], 1), wcs_out, shape_out, r, 1)
+        exp = O.reproject(wcs_in, (shape_in[0], shape_in[1], 1), src[s_lo:s_hi].cpu().numpy()[None], wcs_out, shape_out,
+                          src_row0=s_lo, src_nrows=s_hi - s_lo, dst_row0=r, dst_nrows=1)
+        got = out.data[r:r + 1].cpu().numpy()[None]
+        assert np.array_equal(got.view(np.int64), exp.view(np.int64)), r
+
+
+def test_strip_reprojector_alloc_maps(pj, dev):
+    shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 2400, dims=(2,))
+    shape_out, wcs_out = pj.fullsky_geometry(2 * math.pi / 4800)
+    sh = pj.DecStripReprojector(shape_in, wcs_in, shape_out, wcs_out, 0, 1, dev)
+    for policy in ("class-aware", "plain"):
+        src, dst, info = sh.alloc_maps(policy=policy)
+        assert tuple(src.shape) == tuple(sh.src_tensor_shape()) and tuple(dst.shape) == tuple(sh.dst_tensor_shape())
+        assert info["policy"] == policy and float(src.abs().max()) == 0.0
+        lo_s, hi_s, lo_d, hi_d = src.data_ptr(), src.data_ptr() + src.numel() * 8, dst.data_ptr(), dst.data_ptr() + dst.numel() * 8
+        assert hi_s <= lo_d or hi_d <= lo_s
+        del src, dst, info

@@ -5,16 +5,19 @@
 // tables, NO LDS, NO interpolation and NO wave-uniform bookkeeping: source rows go straight into a register ring D rows deep
 // (fully unrolled, counted vmcnt waits), the stores replicate the lane's own registers.  What this launch takes is what the
 // memory system charges for the traffic mix itself; what k_reproject_dma takes beyond it is the kernel's own doing.
-//   mode 0: loads + stores   1: stores only   2: loads only (a value-dependent, never-taken store keeps them alive)
 //   hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/research/mix_ceiling.hip -o tools/research/libmix_ceiling.so
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-template <int D, int MODE>
+// W = 1-KiB stores per output row (tile width 128 W columns); source row segment = W/2 loads of 16 B per lane
+// MODE 0: loads + stores   1: stores only   2: loads only   3: loads + non-temporal stores
+template <int D, int MODE, int W>
 __global__ __launch_bounds__(64) void k_mix(const double* __restrict__ src, double* __restrict__ dst, int64_t nx, int64_t ny,
                                             int64_t nxo, int64_t nyo, int rh, int ntx, int nty, int64_t ntiles, int64_t xchunk) {
+    constexpr int L = W / 2;
+    constexpr int TW = 128 * W;
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.x;
     const int64_t v = b & 7, j = b >> 3;
@@ -23,64 +26,79 @@ __global__ __launch_bounds__(64) void k_mix(const double* __restrict__ src, doub
     if (t >= ntiles) return;
     const int tx = (int)(t % ntx);
     const int ty = (int)(t / ntx);
-    const int64_t c0 = (int64_t)tx * 512;
-    if (c0 + 512 > nxo) return;                    // whole tiles only (43200 = 84 * 512 + 192: the remainder is left out, 0.4 %)
+    const int64_t c0 = (int64_t)tx * TW;
+    if (c0 + TW > nxo) return;                     // whole tiles only (the remainder of a row is left out: < 1 %)
     const int64_t rb = (int64_t)ty * rh;
     if (rb + rh > nyo || (rb + rh) / 2 > ny) return;   // whole tiles only
     const int nsrc = rh / 2;                       // source rows this tile reads (rh is a multiple of 2 D)
     const int64_t sr0 = rb / 2;
     const double* sp = src + sr0 * nx + c0 / 2 + 2 * lane;
     double* op = dst + rb * nxo + c0 + 2 * lane;
-    d2 ring[D][2];
+    d2 ring[D][L];
     if (MODE != 1) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            ring[k][0] = *reinterpret_cast<const d2*>(sp + (int64_t)k * nx);
-            ring[k][1] = *reinterpret_cast<const d2*>(sp + (int64_t)k * nx + 128);
-        }
+        for (int k = 0; k < D; ++k)
+#pragma unroll
+            for (int l = 0; l < L; ++l) ring[k][l] = *reinterpret_cast<const d2*>(sp + (int64_t)k * nx + 128 * l);
     } else {
 #pragma unroll
-        for (int k = 0; k < D; ++k) { ring[k][0] = d2{1.0, 2.0}; ring[k][1] = d2{3.0, 4.0}; }
+        for (int k = 0; k < D; ++k)
+#pragma unroll
+            for (int l = 0; l < L; ++l) ring[k][l] = d2{1.0 + l, 2.0};
     }
-    auto put = [&](d2 a, d2 bb, double* o) {
+    auto put = [&](const d2 (&a)[L], double* o) {
         if (MODE == 2) {
-            if (a.x == 1.2345e30 && bb.y == 2.5e-30) o[0] = a.y;
+            bool hit = true;
+#pragma unroll
+            for (int l = 0; l < L; ++l) hit = hit && (a[l].x == 1.2345e30);
+            if (hit) o[0] = a[0].y;
         } else {
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                *reinterpret_cast<d2*>(o + r * nxo) = d2{a.x, a.x};
-                *reinterpret_cast<d2*>(o + r * nxo + 128) = d2{a.y, a.y};
-                *reinterpret_cast<d2*>(o + r * nxo + 256) = d2{bb.x, bb.x};
-                *reinterpret_cast<d2*>(o + r * nxo + 384) = d2{bb.y, bb.y};
-            }
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    const d2 lo = d2{a[l].x, a[l].x}, hi = d2{a[l].y, a[l].y};
+                    if (MODE == 3) {
+                        __builtin_nontemporal_store(lo, reinterpret_cast<d2*>(o + r * nxo + 256 * l));
+                        __builtin_nontemporal_store(hi, reinterpret_cast<d2*>(o + r * nxo + 256 * l + 128));
+                    } else {
+                        *reinterpret_cast<d2*>(o + r * nxo + 256 * l) = lo;
+                        *reinterpret_cast<d2*>(o + r * nxo + 256 * l + 128) = hi;
+                    }
+                }
         }
     };
     int s0 = 0;
     for (; s0 + D < nsrc; s0 += D) {               // steady state: no conditionals, so the compiler counts its vmcnt waits
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-            const d2 a = ring[k][0], bb = ring[k][1];
+            d2 a[L];
+#pragma unroll
+            for (int l = 0; l < L; ++l) a[l] = ring[k][l];
             if (MODE != 1) {
-                ring[k][0] = *reinterpret_cast<const d2*>(sp + (int64_t)(s0 + k + D) * nx);
-                ring[k][1] = *reinterpret_cast<const d2*>(sp + (int64_t)(s0 + k + D) * nx + 128);
+#pragma unroll
+                for (int l = 0; l < L; ++l) ring[k][l] = *reinterpret_cast<const d2*>(sp + (int64_t)(s0 + k + D) * nx + 128 * l);
             }
-            put(a, bb, op + (int64_t)(2 * (s0 + k)) * nxo);
+            put(a, op + (int64_t)(2 * (s0 + k)) * nxo);
         }
     }
 #pragma unroll
-    for (int k = 0; k < D; ++k) put(ring[k][0], ring[k][1], op + (int64_t)(2 * (s0 + k)) * nxo);
+    for (int k = 0; k < D; ++k) put(ring[k], op + (int64_t)(2 * (s0 + k)) * nxo);
 }
 
 extern "C" int mix_launch(const double* src, double* dst, int64_t nx, int64_t ny, int64_t nxo, int64_t nyo, int rh, int depth,
-                          int mode, void* stream) {
-    const int ntx = (int)((nxo + 511) / 512), nty = (int)((nyo + rh - 1) / rh);
+                          int mode, int width, void* stream) {
+    const int tw = 128 * width;
+    const int ntx = (int)((nxo + tw - 1) / tw), nty = (int)((nyo + rh - 1) / rh);
     const int64_t ntiles = (int64_t)ntx * nty;
     const int64_t xchunk = (ntiles + 7) / 8;
     const int64_t grid = xchunk * 8;
+    if (rh % (2 * depth) != 0) return -2;
     hipStream_t st = (hipStream_t)stream;
-#define CASE(DD, MM) if (depth == DD && mode == MM) { hipLaunchKernelGGL((k_mix<DD, MM>), dim3((unsigned)grid), dim3(64), 0, st, src, dst, nx, ny, nxo, nyo, rh, ntx, nty, ntiles, xchunk); return (int)hipGetLastError(); }
-    CASE(2, 0) CASE(4, 0) CASE(6, 0) CASE(8, 0)
-    CASE(4, 1) CASE(4, 2) CASE(8, 2)
+#define CASE(DD, MM, WW) if (depth == DD && mode == MM && width == WW) { hipLaunchKernelGGL((k_mix<DD, MM, WW>), dim3((unsigned)grid), dim3(64), 0, st, src, dst, nx, ny, nxo, nyo, rh, ntx, nty, ntiles, xchunk); return (int)hipGetLastError(); }
+    CASE(2, 0, 4) CASE(4, 0, 4) CASE(8, 0, 4)
+    CASE(4, 1, 4) CASE(4, 2, 4) CASE(8, 2, 4)
+    CASE(4, 0, 2) CASE(4, 0, 8) CASE(2, 0, 8) CASE(4, 3, 4) CASE(4, 1, 8) CASE(4, 1, 2)
 #undef CASE
     return -1;
 }

@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--workload", default="cfg3")
     args = ap.parse_args()
     lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmix_ceiling.so"))
-    lib.mix_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.mix_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.mix_launch.restype = C.c_int
     dev = torch.device("cuda:0")
     shape_in, wcs_in, shape_out, wcs_out, desc = bench.workload_geometry(args.workload)
@@ -51,15 +51,20 @@ def main():
     def real():
         plan.execute(src, dst)
 
-    def mix(rh, depth, mode):
+    def mix(rh, depth, mode, width=4):
         def f():
-            rc = lib.mix_launch(src.data_ptr(), dst.data_ptr(), nx, ny, nxo, nyo, rh, depth, mode, C.c_void_p(stream.cuda_stream))
+            rc = lib.mix_launch(src.data_ptr(), dst.data_ptr(), nx, ny, nxo, nyo, rh, depth, mode, width, C.c_void_p(stream.cuda_stream))
             assert rc == 0, rc
         return f
 
     variants = [("k_reproject_dma (the product kernel, bit-exact output)", real)]
-    for rh, depth in ((32, 4), (32, 8), (64, 8), (16, 4), (64, 4), (32, 2)):
+    for rh, depth in ((32, 4), (32, 8), (64, 8), (16, 4), (64, 4), (32, 2), (8, 4), (8, 2), (16, 2), (16, 8)):
         variants.append(("mix loads+stores rh=%d depth=%d" % (rh, depth), mix(rh, depth, 0)))
+    for rh, depth, width in ((16, 4, 2), (32, 4, 2), (16, 4, 8), (32, 4, 8), (8, 2, 8)):
+        variants.append(("mix loads+stores rh=%d depth=%d, %d-column tiles" % (rh, depth, 128 * width), mix(rh, depth, 0, width)))
+    variants.append(("mix loads + NON-TEMPORAL stores rh=16 depth=4", mix(16, 4, 3)))
+    variants.append(("mix stores only rh=32, 256-column tiles", mix(32, 4, 1, 2)))
+    variants.append(("mix stores only rh=32, 1024-column tiles", mix(32, 4, 1, 8)))
     variants.append(("mix stores only rh=32", mix(32, 4, 1)))
     variants.append(("mix loads only rh=32 depth=4", mix(32, 4, 2)))
     variants.append(("mix loads only rh=32 depth=8", mix(32, 8, 2)))
