@@ -675,7 +675,12 @@ int pxl_reproject_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[
     // non-temporal stores keep the column tables in the L2 (pxl_reproject_dma.h).  Measured (profiles/r03_tune_nt.txt): +0.5-0.7 % on
     // the 22 GB same-resolution IQU launch and +1.5 % when down-sampling 2x, but -1.7 % at 2x refinement and -2.4 ... -5 % on
     // launches of a few GB (a 1/8 strip, the 1' map), whose tables stay in the L2 anyway: -1 = by launch size at execute time
-    pl->nt = env_int("PXL_REPROJECT_NT", sx > 0.55 ? -1 : 0);
+    // Round 4 (profiles/r04_tune_rh_nt.txt, the kernel with the prefetch distance counted in source rows): at 2x refinement and beyond
+    // non-temporal stores now WIN wherever the output is not cache resident -- +17 % on a 1/8 declination strip of the 1' -> 0.5'
+    // refinement (0.213 -> 0.182 ms: what a rank of a sharded job runs), +2.7 % at 4x, +1.3 % on the IQU map onto the 0.25' grid,
+    // +0.3 % on the whole 1' map in a two-class placement (equal within noise in a one-class one); the 268 MB output of config 2
+    // measures the same either way: -2 = refinement rule at execute time (nt when the launch writes >= 512 MB)
+    pl->nt = env_int("PXL_REPROJECT_NT", sx > 0.55 ? -1 : -2);
     if (pl->pf < 0) pl->pf = 0;
     const int max_seg = PXL_MAXCH * 128;
     auto seg_for = [&](int pairs) -> int64_t {
@@ -807,7 +812,10 @@ static int reproject_rows_impl(pxl_reproject_plan* pl, const void* src, void* ds
         // LDS-DMA fast path; shrink the ring if it would not fit a CU's LDS comfortably
         const size_t esz = f32 ? 4 : 8;
         p.ns = pl->ns; p.pf = pl->pf; p.zero_page = pl->zero_page;
-        p.nt = pl->nt >= 0 ? pl->nt : ((double)nr * (double)pl->nxo * (double)pl->nc * (f32 ? 4.0 : 8.0) >= 12e9 ? 1 : 0);
+        {
+            const double wbytes = (double)nr * (double)pl->nxo * (double)pl->nc * (f32 ? 4.0 : 8.0);
+            p.nt = pl->nt >= 0 ? pl->nt : (wbytes >= (pl->nt == -2 ? 512e6 : 12e9) ? 1 : 0);
+        }
         while ((size_t)p.ns * p.seg * esz > (size_t)pl->ring_kb * 1024 && p.ns > 4) p.ns >>= 1;   // 17 KiB: >= 9 waves per CU
         size_t dma_lds = (size_t)p.ns * (size_t)p.seg * esz;
         const int nch = (p.seg + cw - 1) / cw;

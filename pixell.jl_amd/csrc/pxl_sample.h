@@ -37,6 +37,21 @@ __device__ inline void generic_store(const GenericParams& p, int64_t t, double x
     // interior cell (all four taps inside the map, or wrapping once on a periodic one): two row offsets, no per-tap checks
     const bool jin = j0 >= 1 && j0 < p.ny;
     const bool iin = p.periodic ? (i0 >= 0 && i0 <= p.nx) : (i0 >= 1 && i0 < p.nx);
+#ifdef PXL_GENERIC_PAIR_TAPS
+    // the two taps of a row are adjacent in memory unless the cell straddles the seam: ONE 16-byte load per row (8-byte aligned)
+    if (visible && fin && jin && i0 >= 1 && i0 < p.nx) {
+        struct __attribute__((packed, aligned(8))) Pair { double a, b; };
+        const int64_t o = (int64_t)(j0 - 1) * p.nx + (i0 - 1);
+        for (int c = 0; c < p.nc; ++c) {
+            const double* pl = p.src + (int64_t)c * p.nx * p.ny;
+            const Pair tp = *reinterpret_cast<const Pair*>(pl + o), bt = *reinterpret_cast<const Pair*>(pl + o + p.nx);
+            const double top = (1 - fx) * tp.a + fx * tp.b;
+            const double bot = (1 - fx) * bt.a + fx * bt.b;
+            p.dst[(int64_t)c * total + t] = (1 - fy) * top + fy * bot;
+        }
+        return;
+    }
+#endif
     if (visible && fin && jin && iin) {
         const int64_t ia = (i0 >= 1 ? i0 : p.nx) - 1, ib = (i0 < p.nx ? i0 + 1 : 1) - 1;       // 0-based columns of i0, i0 + 1
         const int64_t ra = (int64_t)(j0 - 1) * p.nx, rb = ra + p.nx;
@@ -293,7 +308,10 @@ __global__ __launch_bounds__(256) void k_reproject_generic_tiled2(GenericParams 
         *x = sx; *y = sy;
     };
     uint32_t slow_rows = 0;                      // wave-uniform: rows of this wave that could not take the fast path
-#pragma unroll 2
+#ifndef PXL_T2_UNROLL
+#define PXL_T2_UNROLL 2
+#endif
+#pragma unroll PXL_T2_UNROLL
     for (int q = 0; q < PXL_TH / 4; ++q) {
         const int r = w + 4 * q;
         const int64_t jr = tj0 + r;
@@ -460,7 +478,7 @@ __global__ __launch_bounds__(256) void k_sample_bilinear(Sky2Pix s, const T* __r
 // the whole 2x2 neighbourhood of a point is two ADJACENT 2-element entries, kept inside one sector by the grouping
 // below: one random sector per point, for 8/3 of the map's footprint (288 GB of HBM is there to be used) and one
 // streaming pass to build it.  Same taps, same arithmetic: results are bit-identical to k_sample_bilinear.
-// What bounds it (tools/native/exp_random_reach.cpp, exp_scalar_gather.cpp): the memory system serves ~54 G random
+// What bounds it (tools/research/exp_random_reach.cpp, exp_scalar_gather.cpp): the memory system serves ~54 G random
 // 64-byte requests per second whatever the footprint (128 MiB ... 48 GiB, Infinity Cache or HBM, vector and scalar
 // path together), and ~38 G cells/s when the coordinate and result streams share it; this kernel reaches 31-33.
 template <typename T> struct Vec2T;

@@ -1,7 +1,7 @@
 // pxl_spread.h -- the placement probe; included by pxl_kernels.hip.
 //
 // Round 3 found what makes "the same" 7-22 GB destination 10-17 % faster in some places than in others
-// (tools/native/exp_xcd_affinity.cpp, exp_vmm_vs_malloc.cpp; profiles/r03_xcd_classes.txt): the memory of a hipMalloc'ed
+// (tools/research/exp_xcd_affinity.cpp, exp_vmm_vs_malloc.cpp; profiles/r03_xcd_classes.txt): the memory of a hipMalloc'ed
 // allocation falls into three classes -- any two 1 GiB windows are cleanly either "of one class" or "of different classes", an
 // equivalence relation with three classes of up to 96 GiB each, i.e. the thirds of the 288 GiB part (the three ranks of its
 // 12-high HBM3E stacks is our reading; nothing here depends on the name) -- and a kernel that keeps several far-apart WRITE

@@ -208,7 +208,7 @@ class DecStripReprojector(DecStripLayout):
     def alloc_pair(self, dtype=torch.float64):
         """Source and destination buffers carved out of ONE device allocation, destination above the source on a 2 MiB
         boundary.  Where the write stream lands physically moves the reprojection by up to 8 % (stores alone: 3.2 vs 3.7
-        ms for 22 GB, same kernel; tools/native/exp_placement_vmm.cpp, profiles/r02_placement_arena.jsonl).  For the
+        ms for 22 GB, same kernel; tools/research/exp_placement_vmm.cpp, profiles/r02_placement_arena.jsonl).  For the
         0.5-arcmin IQU map this arrangement measured 7.2-7.37 ms in 20 of 24 processes on 9 boxes (two allocations: 7.2-8.1,
         about half of them slow, on some boxes every time); for the 2x-refinement workloads it is within 1 % of two
         allocations either way (profiles/r02_ab_arena_*.txt).  bench.py allocates through it.

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 evidence (run through gpurun from the repo root): tools/collect_r03.sh [tag]
+# Round-3 evidence (run through gpurun from the repo root): tools/research/collect_r03.sh [tag]
 #   un-profiled default bench line (headline + configs), then per workload: the same command under
 #   rocprofv3 --kernel-trace --stats (program directly after --) and the two HBM-traffic counter passes
 #   (--pmc FETCH_SIZE / --pmc WRITE_SIZE, kernel-trace only, separate passes).  Everything under gpurun_out/<tag>/.

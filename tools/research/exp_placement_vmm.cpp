@@ -5,7 +5,7 @@
 //   vmm         hipMemAddressReserve + one hipMemCreate / hipMemMap per 2 MiB (minimum granularity), per 64 MiB, per 512 MiB
 //               (hipMemSetAccess refused 1 GiB and larger handles on this ROCm build)
 // Prints one JSON line per trial.  No Python, no torch: the C ABI alone.
-//   hipcc --offload-arch=gfx950 -O2 -I include tools/native/exp_placement_vmm.cpp -L pixell.jl_amd -lpixell_hip \
+//   hipcc --offload-arch=gfx950 -O2 -I include tools/research/exp_placement_vmm.cpp -L pixell.jl_amd -lpixell_hip \
 //         -Wl,-rpath,$PWD/pixell.jl_amd -o exp_placement_vmm && ./exp_placement_vmm 4
 #include <hip/hip_runtime.h>
 #include <cmath>

@@ -2,7 +2,7 @@
 // the Infinity Cache and the address translation stop helping?  Each lane issues rounds of 8 independent random accesses;
 // an access is one 8-byte load, or a 32-byte "cell" (two adjacent 16-byte loads, 16-byte aligned: what a 2x2 bilinear
 // neighbourhood costs in the row-pair layout).  Prints G accesses/s.
-//   hipcc --offload-arch=gfx950 -O2 tools/native/exp_random_reach.cpp -o tools/native/exp_random_reach
+//   hipcc --offload-arch=gfx950 -O2 tools/research/exp_random_reach.cpp -o tools/research/exp_random_reach
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

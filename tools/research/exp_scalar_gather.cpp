@@ -2,7 +2,7 @@
 // throughput on top of what the vector path (TA / TCP) delivers?  The scattered sampler (config 5) is bound by the rate of
 // per-lane divergent accesses; scalar loads do not go through the TCP.  Measures random 8-byte loads per second from buffers
 // of several sizes: per lane (vector), per wave (scalar, 8 or 16 in flight) and both kinds at once.
-//   hipcc --offload-arch=gfx950 -O2 tools/native/exp_scalar_gather.cpp -o tools/native/exp_scalar_gather
+//   hipcc --offload-arch=gfx950 -O2 tools/research/exp_scalar_gather.cpp -o tools/research/exp_scalar_gather
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

@@ -1,5 +1,5 @@
 // exp_vmm_classes.cpp -- what distinguishes the physical regions in which the reprojection's destination is fast?
-// Round 3: sliding the destination through one 220 GiB allocation (tools/exp_scan_placement.py) shows the kernel's stores
+// Round 3: sliding the destination through one 220 GiB allocation (tools/research/exp_scan_placement.py) shows the kernel's stores
 // running at 7.0 instead of 6.0 TB/s exactly when the destination STRADDLES a boundary between two regions of the
 // allocation (boundaries every 32 GiB, denser near the allocation's end), fastest with the boundary in the middle.
 // This host builds the destination out of separately created physical handles (hipMemCreate / hipMemMap) instead:
@@ -9,8 +9,8 @@
 //   policy  destination = alternating handles of two pools created with a ballast of G GiB between them (what an
 //           allocator could do without probing anything), against the plain order
 // Workload: the 1' -> 0.5' refinement (config 3), stores only and the full launch.  One JSON line per measurement.
-//   hipcc --offload-arch=gfx950 -O2 -I include tools/native/exp_vmm_classes.cpp -L pixell.jl_amd -lpixell_hip \
-//         -Wl,-rpath,$PWD/pixell.jl_amd -o tools/native/exp_vmm_classes && tools/native/exp_vmm_classes scan 400
+//   hipcc --offload-arch=gfx950 -O2 -I include tools/research/exp_vmm_classes.cpp -L pixell.jl_amd -lpixell_hip \
+//         -Wl,-rpath,$PWD/pixell.jl_amd -o tools/research/exp_vmm_classes && tools/research/exp_vmm_classes scan 400
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>

@@ -2,7 +2,7 @@
 // each XCD v (workgroups with blockIdx % 8 == v run on one XCD; the others exit at once): the rate of a plain 16-byte-per-lane
 // store stream of that XCD alone into the window; then all eight XCDs into ONE window, and into EIGHT windows (XCD v -> window
 // (v + shift) % 8) -- the shape of the reprojection's eight write fronts.  Prints one JSON line per measurement.
-//   hipcc --offload-arch=gfx950 -O2 tools/native/exp_xcd_affinity.cpp -o tools/native/exp_xcd_affinity && tools/native/exp_xcd_affinity 224 32
+//   hipcc --offload-arch=gfx950 -O2 tools/research/exp_xcd_affinity.cpp -o tools/research/exp_xcd_affinity && tools/research/exp_xcd_affinity 224 32
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Per-channel view of the same two store-only cases as tools/pmc_store_regions.sh (un-summed TCC counters).
+# Per-channel view of the same two store-only cases as tools/research/pmc_store_regions.sh (un-summed TCC counters).
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/r02_store_channels
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-exe=$R/tools/native/exp_placement_vmm
+exe=$R/tools/research/exp_placement_vmm
 i=0
 for grp in "TCC_EA0_WRREQ" "TCC_BUSY" "TCC_EA0_WRREQ_STALL"; do
   i=$((i+1))

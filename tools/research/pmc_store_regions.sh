@@ -1,12 +1,12 @@
 #!/bin/bash
-# Counters of the reprojection kernel's STORES into the two halves of one 45 GB allocation (tools/native/exp_placement_vmm pmc):
+# Counters of the reprojection kernel's STORES into the two halves of one 45 GB allocation (tools/research/exp_placement_vmm pmc):
 # which part of the memory system tells a fast-writing region from a slow one?  One rocprofv3 pass per counter group.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/r02_store_regions
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-exe=$R/tools/native/exp_placement_vmm
+exe=$R/tools/research/exp_placement_vmm
 $exe 1 pmc > $out/plain.jsonl 2>&1; cat $out/plain.jsonl
 i=0
 for grp in "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_LEVEL_sum" \
