@@ -141,6 +141,7 @@ struct UnwindWs {
     int32_t* flag;                                              // [0],[1]: multi-pass verification; [2]: fused path failed
     unsigned long long* firstnan;                               // first NaN of each coordinate row
     int2* wsum; double2* wprev;                                 // fused form: per wave chunk
+    UwLink* links; unsigned int* ticket; int64_t nlinks;        // one-pass form: one link per workgroup chunk
     int64_t nb, nw;
     int U;                                                      // points per wave chunk / 64
     bool multipass;                                             // per-element scratch of the multi-pass fallback present
@@ -191,7 +192,9 @@ static int unwind_ws_alloc(int64_t n, int nrow, hipStream_t st, UnwindWs* w) {
     const size_t bytes_c = w->multipass ? up((size_t)nrow * n) : 0, bytes_r = w->multipass ? up((size_t)4 * nrow * n) : 0,
                  bytes_b = w->multipass ? up((size_t)4 * nrow * w->nb) : 0;
     const size_t bytes_ws = up((size_t)w->nw * sizeof(int2)), bytes_wp = up((size_t)w->nw * sizeof(double2));
-    const size_t total = bytes_c + bytes_r + 2 * bytes_b + bytes_ws + bytes_wp + 256;
+    w->nlinks = (n + 64 * PXL_UW1_U * PXL_UW1_WAVES - 1) / (64 * PXL_UW1_U * PXL_UW1_WAVES);
+    const size_t bytes_ln = up((size_t)w->nlinks * sizeof(UwLink) + 16);
+    const size_t total = bytes_c + bytes_r + 2 * bytes_b + bytes_ws + bytes_wp + bytes_ln + 256;
     w->base = nullptr;
     hipMemPool_t pool = unwind_pool();
     if (pool) HIP_TRY(hipMallocFromPoolAsync((void**)&w->base, total, pool, st));
@@ -203,6 +206,7 @@ static int unwind_ws_alloc(int64_t n, int nrow, hipStream_t st, UnwindWs* w) {
     w->boff = (int32_t*)p; p += bytes_b;
     w->wsum = (int2*)p; p += bytes_ws;
     w->wprev = (double2*)p; p += bytes_wp;
+    w->links = (UwLink*)p; w->ticket = (unsigned int*)(p + (size_t)w->nlinks * sizeof(UwLink)); p += bytes_ln;
     w->flag = (int32_t*)p;
     w->firstnan = (unsigned long long*)(p + 16);
     if (hipMemsetAsync(w->flag, 0, 32, st) != hipSuccess) {      // flags and the (complemented) first-NaN indices
@@ -236,6 +240,17 @@ static int unwind_fused(const SRC& src, typename SRC::raw_t* out, int64_t n, boo
                            (const double2*)w.wprev, (const unsigned long long*)w.firstnan, fastflag, (const int32_t*)nullptr);
     }
     return check_launch("k_unwind fused");
+}
+
+// One-pass form (k_unwind_onepass: decoupled look-back; out-of-place calls only).  The links and the ticket are zeroed on the
+// stream before the launch; the failure flag is the fused path's, so the same fallbacks follow.
+template <class SRC>
+static int unwind_onepass(const SRC& src, typename SRC::raw_t* out, int64_t n, UnwindWs& w, hipStream_t st) {
+    if (w.nlinks > 0x7fffffffLL) return fail(PXL_EINVAL, "unwind: batch too long");
+    hipError_t e = hipMemsetAsync(w.links, 0, (size_t)w.nlinks * sizeof(UwLink) + 16, st);
+    if (e != hipSuccess) return fail(PXL_EHIP, "unwind: hipMemsetAsync: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL((k_unwind_onepass<SRC>), dim3((unsigned)w.nlinks), dim3(64 * PXL_UW1_WAVES), 0, st, src, out, n, w.links, w.ticket, w.flag + 2);
+    return check_launch("k_unwind_onepass");
 }
 
 // Multi-pass form on a buffer that already holds m = rewind(.) - ref (see k_unwrap_* in pxl_unwrap.h).  With
@@ -367,7 +382,9 @@ int pxl_pix2sky_car_f64(const pxl_car_wcs* wcs, int64_t n, const double* pix, do
     int rc = unwind_ws_alloc(n, 2, st, &w);
     if (rc) return rc;
     UwSrcPix2 src{c, (const double2*)pix, PXL_TWOPI_D, 0.0, 1.0 / PXL_TWOPI_D};
-    rc = unwind_fused(src, (double2*)sky, n, pa == sa, w, st);
+    // out of place: one pass (input read once, the exact rewind evaluated once); in place: sums -> scan -> verify -> store
+    if (pa != sa && env_int("PXL_UNWIND_ONEPASS", 1)) rc = unwind_onepass(src, (double2*)sky, n, w, st);
+    else rc = unwind_fused(src, (double2*)sky, n, pa == sa, w, st);
     if (rc == PXL_OK) {
         const int32_t* failed = w.flag + 2;
         if (!w.multipass) {
@@ -566,6 +583,22 @@ int pxl_posmap_tan_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64_t r
     const int64_t nrb = (nrows + PXL_TAN_ROWS - 1) / PXL_TAN_ROWS;   // PXL_TAN_ROWS rows per block
     if (nchunk * nrb > 0x7fffffffLL) return fail(PXL_EINVAL, "posmap_tan: map too large for one launch");
     const bool vec = (shape[0] % 2 == 0) && ((((uintptr_t)ra | (uintptr_t)dec) & 15) == 0);
+    // maps of at least one tile: the grid form (anchors + closed-form differences + interpolation, pxl_tan.h); PXL_TAN_GRID=0 or a
+    // small map: the per-pixel evaluation
+    // The grid form pays when a 128-column tile spans at most ~2 degrees (pixels up to ~1 arcmin: beyond that the degree-8 interpolant
+    // misses its 2^-55 rad check and the rows fall back to the per-pixel path after paying for the lattice) and the patch centre is
+    // not next to a pole (there most rows fail the small-angle preconditions)
+    const TanParams tp0 = tan_setup(*wcs);
+    const bool grid_pays = fabs(tp0.uos) * PXL_TG_W <= 0.04 && fabs(tp0.cd0) >= 0.3;
+    if (env_int("PXL_TAN_GRID", grid_pays ? 1 : 0) && shape[0] >= PXL_TG_W && nrows >= 8) {
+        const int64_t ntx = (shape[0] + PXL_TG_W - 1) / PXL_TG_W, nty = (nrows + PXL_TG_ROWS - 1) / PXL_TG_ROWS;
+        const int64_t nblk = (ntx * nty + 3) / 4;
+        if (nblk <= 0x7fffffffLL) {
+            if (vec) hipLaunchKernelGGL((k_posmap_tan_grid<true>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, tan_setup(*wcs), shape[0], row0, nrows, ntx, ra, dec);
+            else     hipLaunchKernelGGL((k_posmap_tan_grid<false>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, tan_setup(*wcs), shape[0], row0, nrows, ntx, ra, dec);
+            return check_launch("k_posmap_tan_grid");
+        }
+    }
     const dim3 grid((unsigned)(nchunk * nrb));
     if (vec) hipLaunchKernelGGL((k_posmap_tan<true>), grid, dim3(256), 0, (hipStream_t)stream, tan_setup(*wcs), shape[0], row0, nrows, nchunk, ra, dec);
     else     hipLaunchKernelGGL((k_posmap_tan<false>), grid, dim3(256), 0, (hipStream_t)stream, tan_setup(*wcs), shape[0], row0, nrows, nchunk, ra, dec);
@@ -644,7 +677,10 @@ int pxl_reproject_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[
     // the 2x refinement prefers 32 by 1.5 %)
     // Other scale factors (round 3, profiles/r03_tune_other3_*.txt): 4x refinement 8 rows (81.8 % against 75.2 % with 32; 16: 80.2 %),
     // 2x coarsening 4 rows (75.4 % against 73.2 % with 16)
-    pl->rh = env_int("PXL_REPROJECT_RH", sy >= 1.5 ? 4 : (sy >= 0.75 ? 16 : (sy > 0.3 ? 32 : 8)));
+    // Round 4, timed in BURSTS of one plan (a launch's stores leave the caches in a state that moves the next launch by 2-20 %, so
+    // interleaving single launches of different variants misleads; profiles/r04_tune_nt_bursts.txt): with non-temporal stores the 2x
+    // refinement prefers 16 rows as well (1.486 -> 1.453 ms = 80.3 % on placed maps, 1.726 -> 1.713 in a one-class placement; strips equal)
+    pl->rh = env_int("PXL_REPROJECT_RH", sy >= 1.5 ? 4 : (sy > 0.3 ? 16 : 8));
     if (pl->rh < 1) pl->rh = 1;
     if (pl->rh > 64) pl->rh = 64;          // one lane per tile row holds the row-table entry
     pl->rh32 = env_int("PXL_REPROJECT_RH", 32);      // Float32 maps (4 pixels per lane) prefer 32 in both regimes
@@ -680,7 +716,12 @@ int pxl_reproject_plan_create(const pxl_car_wcs* wcs_in, const int64_t shape_in[
     // refinement (0.213 -> 0.182 ms: what a rank of a sharded job runs), +2.7 % at 4x, +1.3 % on the IQU map onto the 0.25' grid,
     // +0.3 % on the whole 1' map in a two-class placement (equal within noise in a one-class one); the 268 MB output of config 2
     // measures the same either way: -2 = refinement rule at execute time (nt when the launch writes >= 512 MB)
-    pl->nt = env_int("PXL_REPROJECT_NT", sx > 0.55 ? -1 : -2);
+    // ... and measured in bursts (the steady state of a caller repeating one plan, which is also what bench.py times) non-temporal
+    // stores win on EVERY launch: 1/8 strip of the 2x refinement 0.225 -> 0.180 ms, config 2 (cache resident) 0.079 -> 0.064 ms, the 1'
+    // same-resolution map 0.664 -> 0.656 ms, a 1/8 strip of the IQU map 1.029 -> 1.017 ms, 4x refinement +2.3 %.  The earlier "-2.4 ...
+    // -5 % on launches of a few GB" was the interleaving artefact: an nt launch timed behind a plain-store launch pays for that
+    // launch's dirty lines.  1 = always.
+    pl->nt = env_int("PXL_REPROJECT_NT", 1);
     if (pl->pf < 0) pl->pf = 0;
     const int max_seg = PXL_MAXCH * 128;
     auto seg_for = [&](int pairs) -> int64_t {
@@ -1119,7 +1160,10 @@ int pxl_reproject_generic_bilinear_f64(const pxl_car_wcs* wcs_in, int proj_in, c
     double2* lat = (double2*)ws;
     int32_t* flag = (int32_t*)(ws + lat_bytes);
     hipLaunchKernelGGL(k_generic_lattice, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, p, gx, ntiles, lat, flag);
-    if (env_int("PXL_GENERIC_V1", 0))       // round 3's pixel kernel (one pixel per lane, 8-byte taps and stores): kept for A/B
+    const int gv = env_int("PXL_GENERIC_V", 3);
+    if (gv == 3)
+        hipLaunchKernelGGL(k_reproject_generic_tiled3, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, (const double2*)lat, (const int32_t*)flag);
+    else if (gv == 1 || env_int("PXL_GENERIC_V1", 0))       // round 3's pixel kernel (one pixel per lane, 8-byte taps and stores): kept for A/B
         hipLaunchKernelGGL(k_reproject_generic_tiled, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, (const double2*)lat, (const int32_t*)flag);
     else
         hipLaunchKernelGGL(k_reproject_generic_tiled2, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, (const double2*)lat, (const int32_t*)flag);

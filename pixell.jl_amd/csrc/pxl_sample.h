@@ -100,10 +100,14 @@ __global__ __launch_bounds__(256) void k_reproject_generic(GenericParams p) {
 #ifndef PXL_TNX
 #define PXL_TNX 7          // lattice nodes along a tile's width (degree 6)
 #endif
+#ifndef PXL_TNY
 #define PXL_TNY 6
+#endif
 #define PXL_TCHK0 (PXL_TNX * PXL_TNY <= 40 ? 40 : 48)     // first of the check lanes of a tile's wave
 #define PXL_TNCHK 12                                       // check points per tile (lanes PXL_TCHK0 ... + 11)
+#ifndef PXL_TH
 #define PXL_TH 32          // tile height (output rows)
+#endif
 #ifndef PXL_TW
 #define PXL_TW 128         // tile width (output columns): 64 or 128 (one or two waves side by side in the 256-thread block)
 #endif
@@ -358,6 +362,110 @@ __global__ __launch_bounds__(256) void k_reproject_generic_tiled2(GenericParams 
         coords(r, 1, &xs[1], &ys[1]);
 #pragma unroll 1
         for (int e = 0; e < (two ? 2 : 1); ++e) generic_store(p, t + e, e ? xs[1] : xs[0], e ? ys[1] : ys[0], true);
+    }
+}
+
+// Round 4, third form: one pixel per lane as in round 3's kernel (24 registers of column data, 6 waves per SIMD) with a LEAN
+// interior path.  Round 3's loop costs ~99 VALU instructions per pixel (26 M wave instructions per 4096^2 patch,
+// profiles/r02_tan_mosaic_counters.txt) of which only 12 + 11 are the coordinate interpolation and the blend: the rest is 64-bit
+// index arithmetic, range tests, two isfinite classifications, clamps and per-tap selects -- on a kernel whose FP64-rate
+// instructions alone take 48 us of its 76 us.  Here:
+//   * the cell is floor -> subtract -> v_cvt_i32_f64, which SATURATES out-of-range values and turns NaN into 0: both then fail the
+//     one unsigned range test per axis, so neither clamp nor isfinite is needed on the fast path;
+//   * "all four taps inside, no seam" is (unsigned)(i0 - 1) < nx - 1 and (unsigned)(j0 - 1) < ny - 1;
+//   * the offset is 32-bit when the plane has fewer than 2^31 elements (wave-uniform choice), one 64-bit shift-add per row address;
+//   * the two taps of a row are one 16-byte load (8-byte aligned);
+//   * rows that fail the test anywhere in the wave (seam, edges, horizon, NaN) are redone afterwards by generic_store, one
+//     non-unrolled copy of the general code.
+// Same operations on the same operands as generic_store's interior path: the bits are those of round 3's kernel.
+__global__ __launch_bounds__(256) void k_reproject_generic_tiled3(GenericParams p, const double2* __restrict__ lat,
+                                                                  const int32_t* __restrict__ flag) {
+    const int64_t tile = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const int64_t ti0 = (int64_t)blockIdx.x * PXL_TW, tj0 = (int64_t)blockIdx.y * PXL_TH;   // 0-based tile origin
+    const int tid = threadIdx.x;
+    const int cx = tid & (PXL_TW - 1), ry = __builtin_amdgcn_readfirstlane(tid / PXL_TW);
+    const int64_t i = ti0 + cx;
+    if (i >= p.nxo) return;
+    if (flag[tile]) return;                      // k_reproject_generic_exact_tiles does this tile
+    const double2* L = lat + tile * (PXL_TNX * PXL_TNY);
+    double wx[PXL_TNX];
+#pragma unroll
+    for (int a = 0; a < PXL_TNX; ++a) wx[a] = c_tile_weights.wx[cx][a];
+    double colx[PXL_TNY], coly[PXL_TNY];
+#pragma unroll
+    for (int b = 0; b < PXL_TNY; ++b) {
+        double sx = 0.0, sy = 0.0;
+#pragma unroll
+        for (int a = 0; a < PXL_TNX; ++a) { const double2 v = L[b * PXL_TNX + a]; sx = __builtin_fma(wx[a], v.x, sx); sy = __builtin_fma(wx[a], v.y, sy); }
+        colx[b] = sx; coly[b] = sy;
+    }
+    auto coords = [&](int r, double* x, double* y) {
+        double sx = 0.0, sy = 0.0;
+#pragma unroll
+        for (int b = 0; b < PXL_TNY; ++b) { const double wy = c_tile_weights.wy[r][b]; sx = __builtin_fma(wy, colx[b], sx); sy = __builtin_fma(wy, coly[b], sy); }
+        *x = sx; *y = sy;
+    };
+    const int64_t total = p.nxo * p.nyo;
+    const uint32_t nxm1 = (uint32_t)(p.nx - 1), nym1 = (uint32_t)(p.ny - 1);
+    const int32_t nx32 = (int32_t)p.nx;
+    const bool small = p.nx * p.ny < 0x7fffffffLL && p.nx < 0x7fffffffLL;            // wave-uniform: 32-bit element offsets
+    struct __attribute__((packed, aligned(8))) Pair { double a, b; };
+    uint32_t slow_rows = 0;
+    constexpr int NQ = PXL_TH / PXL_TROWS;
+    // rows in groups of G: the group's 2 G tap loads are issued back to back before the first blend (a row at a time the wave had
+    // two loads in flight and sat in s_waitcnt for 75 % of its cycles, round 3's counters)
+#ifndef PXL_T3_G
+#define PXL_T3_G 4
+#endif
+    constexpr int G = PXL_T3_G;
+#pragma unroll
+    for (int q0 = 0; q0 < NQ; q0 += G) {
+        double fx[G], fy[G];
+        int64_t off[G];
+        bool ok = true;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int r = ry + PXL_TROWS * (q0 + g);
+            double x, y;
+            coords(r, &x, &y);
+            const double flx = floor(x), fly = floor(y);
+            fx[g] = x - flx; fy[g] = y - fly;
+            const int32_t i0 = (int32_t)flx, j0 = (int32_t)fly;                        // saturating; NaN -> 0
+            ok = ok && (uint32_t)(i0 - 1) < nxm1 && (uint32_t)(j0 - 1) < nym1;
+            off[g] = small ? (int64_t)((j0 - 1) * nx32 + (i0 - 1)) : (int64_t)(j0 - 1) * p.nx + (i0 - 1);
+        }
+        const bool inside = tj0 + ry + PXL_TROWS * (q0 + G - 1) < p.nyo;               // wave-uniform: the whole group is inside the map
+        if (inside && __all(ok)) {
+            for (int c = 0; c < p.nc; ++c) {
+                const double* pl = p.src + (int64_t)c * p.nx * p.ny;
+                Pair tp[G], bt[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) { tp[g] = *reinterpret_cast<const Pair*>(pl + off[g]); bt[g] = *reinterpret_cast<const Pair*>(pl + off[g] + p.nx); }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const double top = (1 - fx[g]) * tp[g].a + fx[g] * tp[g].b;
+                    const double bot = (1 - fx[g]) * bt[g].a + fx[g] * bt[g].b;
+                    p.dst[(int64_t)c * total + (tj0 + ry + PXL_TROWS * (q0 + g)) * p.nxo + i] = (1 - fy[g]) * top + fy[g] * bot;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                if (tj0 + ry + PXL_TROWS * (q0 + g) < p.nyo) slow_rows |= 1u << (q0 + g);
+        }
+    }
+#pragma unroll 1
+    while (slow_rows) {
+        const int q = __builtin_ctz(slow_rows);
+        slow_rows &= slow_rows - 1;
+        const int r = ry + PXL_TROWS * q;
+        double x, y;
+        // (compile-time row index for the weights table is lost here: a plain loop over the table)
+        double sx = 0.0, sy = 0.0;
+#pragma unroll
+        for (int b = 0; b < PXL_TNY; ++b) { const double wy = c_tile_weights.wy[r][b]; sx = __builtin_fma(wy, colx[b], sx); sy = __builtin_fma(wy, coly[b], sy); }
+        x = sx; y = sy;
+        generic_store(p, (tj0 + r) * p.nxo + i, x, y, true);
     }
 }
 

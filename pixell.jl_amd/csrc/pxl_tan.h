@@ -152,3 +152,174 @@ __global__ __launch_bounds__(256) void k_posmap_tan(TanParams t, int64_t nx, int
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// posmap of a Gnomonic map, round 4: the trigonometry leaves the pixel loop.
+//
+// k_posmap_tan above spends ~100 FP64 instructions per pixel (a reciprocal square root, an atan2 and an asin) and is bound by
+// their issue, 43 % of the write roofline.  On a GRID the two angles are smooth functions of the column along a row, and the
+// angle between two directions of one row has a closed form that is cheap and exact:
+//      RA_i  - RA_a  = atan( D (X_a - X_i) / (D^2 + X_i X_a) )                                   (D = sin d0 Y + cos d0, the row's)
+//      DEC_i - DEC_a = atan( num (X_a - X_i)(X_a + X_i) / ((rho_a + rho_i)(rho_i rho_a + num^2)) ),   rho = sqrt(X^2 + D^2)
+// (tan of a difference; num = sin d0 - cos d0 Y; tan DEC = num / rho, tan(RA - a0) = -X / D).  For pixels of one 128-column tile
+// the arguments are below 1/16, so each is a 7-term odd series -- accurate to 1e-19 rad because the DIFFERENCE is small.
+// One wave per tile of 128 columns x 64 rows:
+//   phase A (a lane = a row): the row's anchor (RA_a, DEC_a) at tile column 64 by the exact evaluator; the differences at nine
+//            equispaced node columns and at two check columns by the closed forms; the degree-8 interpolant through the nodes is
+//            checked against the closed form at the check columns (tolerance 2^-55 rad); node values go to LDS
+//   phase B (a lane = two adjacent columns, marching down the rows): RA = RA_a + sum_k w[col][k] dRA_k, likewise DEC -- 18 FMAs
+//            per pixel, with the Lagrange weights of the lane's columns in registers and a row's node values read from LDS
+// A row that fails a precondition (D <= 0: beyond the pole, where atan2 has its cut; an argument above 1/16: a tile next to a
+// pole or very coarse pixels; a failed check; non-finite values) is evaluated per pixel by tan_pix2sky_xrow, as before.
+// Error against the exact per-pixel evaluation: the anchor's own (<= 1.5 ulp, shared by the row's 128 pixels) plus one rounding.
+// ------------------------------------------------------------------------------------------------
+#define PXL_TG_W 128
+#define PXL_TG_ROWS 64
+#define PXL_TG_NODES 9
+#define PXL_TG_SMAX 0.0625
+#define PXL_TG_TOL 0x1p-55
+struct TanGridWeights { double w[PXL_TG_W][PXL_TG_NODES]; double chk[2][PXL_TG_NODES]; };
+constexpr double tg_lag(double u, int a) {           // Lagrange basis a of the nodes k * (W - 1) / (NODES - 1) at column u
+    const double h = (PXL_TG_W - 1.0) / (PXL_TG_NODES - 1);
+    double num = 1.0, den = 1.0;
+    for (int c = 0; c < PXL_TG_NODES; ++c)
+        if (c != a) { num *= (u - c * h); den *= ((a - c) * h); }
+    return num / den;
+}
+#define PXL_TG_CHK0 7.5
+#define PXL_TG_CHK1 119.5
+constexpr TanGridWeights make_tan_grid_weights() {
+    TanGridWeights t{};
+    for (int u = 0; u < PXL_TG_W; ++u)
+        for (int a = 0; a < PXL_TG_NODES; ++a) t.w[u][a] = tg_lag((double)u, a);
+    for (int a = 0; a < PXL_TG_NODES; ++a) { t.chk[0][a] = tg_lag(PXL_TG_CHK0, a); t.chk[1][a] = tg_lag(PXL_TG_CHK1, a); }
+    return t;
+}
+__constant__ TanGridWeights c_tan_grid_weights = make_tan_grid_weights();
+
+// atan(s) for |s| <= 1/16: s (1 - z/3 + z^2/5 - ... + z^6/13), z = s^2; the next term is below 2^-60 s
+__device__ inline double tg_atan_small(double s) {
+    const double z = s * s;
+    double p = 1.0 / 13;
+    p = __builtin_fma(p, z, -1.0 / 11);
+    p = __builtin_fma(p, z, 1.0 / 9);
+    p = __builtin_fma(p, z, -1.0 / 7);
+    p = __builtin_fma(p, z, 1.0 / 5);
+    p = __builtin_fma(p, z, -1.0 / 3);
+    return __builtin_fma(s * z, p, s);
+}
+// n / d to <= 1 ulp from the reciprocal seed (d finite, non-zero, ordinary magnitude)
+__device__ inline double tg_div(double n, double d) {
+    double r = pxl_fm_rcp_seed(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    const double q = n * r;
+    return __builtin_fma(__builtin_fma(-d, q, n), r, q);
+}
+// the two differences of a row against the anchor at Xa, at the abscissa Xa - dX; *ok: the preconditions of the small-angle forms.
+// dX comes from the COLUMN difference, (column - 64) * unit/scale, not from a subtraction of two rounded abscissae: the rounding of
+// X itself (half an ulp of ~0.3 rad = 3e-17, i.e. 2e-13 column) would otherwise enter the differences as noise of 1e-16 rad that no
+// smooth interpolant can follow -- a first version failed its own check in 87 % of the rows that way.  In the products below a
+// rounded X is harmless (a relative 1e-16 of a difference of 1e-2 rad).
+__device__ inline void tg_delta(const TanRow& rw, double D2, double N2, double Xa, double rho_a, double dX, double* dra, double* ddec, bool* ok) {
+    const double X = Xa - dX;
+    const double dot = __builtin_fma(X, Xa, D2);
+    const double s = tg_div(rw.den * dX, dot);
+    const double rho = __builtin_sqrt(__builtin_fma(X, X, D2));
+    const double s2 = tg_div((rw.num * dX) * (Xa + X), (rho_a + rho) * __builtin_fma(rho, rho_a, N2));
+    *dra = tg_atan_small(s);
+    *ddec = tg_atan_small(s2);
+    *ok = dot > 0.0 && __builtin_fabs(s) <= PXL_TG_SMAX && __builtin_fabs(s2) <= PXL_TG_SMAX;      // (NaN fails every comparison)
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_posmap_tan_grid(TanParams t, int64_t nx, int64_t row0, int64_t nrows, int64_t ntx,
+                                                         double* __restrict__ ra, double* __restrict__ dec) {
+    __shared__ __attribute__((aligned(16))) double nodes[4][PXL_TG_ROWS][2 * PXL_TG_NODES + 2];      // per wave and row: 9 dRA, 9 dDEC, RA_a, DEC_a
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t tile = (int64_t)blockIdx.x * 4 + w;
+    const int64_t tx = tile % ntx, ty = tile / ntx;
+    const int64_t ti0 = tx * PXL_TG_W, tj0 = ty * PXL_TG_ROWS;                  // tile origin: 0-based column, row within the request
+    if (tj0 >= nrows) return;                                                   // (whole wave; no block-level barrier is used)
+    const int nr = (int)((nrows - tj0) < PXL_TG_ROWS ? (nrows - tj0) : PXL_TG_ROWS);
+    const double h = (PXL_TG_W - 1.0) / (PXL_TG_NODES - 1);
+    // ---- phase A: lane = row
+    bool row_ok = false;
+    {
+        const TanRow rw = tan_row(t, (double)(row0 + tj0 + lane + 1));
+        const double Xa = (t.cpx - (double)(ti0 + PXL_TG_W / 2 + 1)) * t.uos;   // anchor: tile column 64
+        double ra_a, dec_a;
+        tan_pix2sky_xrow<false>(t, rw, Xa, Xa * Xa, &ra_a, &dec_a);
+        const double D2 = rw.den * rw.den, N2 = rw.num * rw.num;
+        const double rho_a = __builtin_sqrt(__builtin_fma(Xa, Xa, D2));
+        bool ok = lane < nr && rw.den > 0.0 && ra_a == ra_a && dec_a == dec_a;
+        double dr[PXL_TG_NODES], dd[PXL_TG_NODES];
+#pragma unroll
+        for (int k = 0; k < PXL_TG_NODES; ++k) {
+            bool o;
+            tg_delta(rw, D2, N2, Xa, rho_a, (k * h - PXL_TG_W / 2) * t.uos, &dr[k], &dd[k], &o);     // column k h of the tile
+            ok = ok && o;
+        }
+        const double chk_col[2] = {PXL_TG_CHK0, PXL_TG_CHK1};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            double er, ed; bool o;
+            tg_delta(rw, D2, N2, Xa, rho_a, (chk_col[q] - PXL_TG_W / 2) * t.uos, &er, &ed, &o);
+            double sr = 0.0, sd = 0.0;
+#pragma unroll
+            for (int k = 0; k < PXL_TG_NODES; ++k) {
+                sr = __builtin_fma(c_tan_grid_weights.chk[q][k], dr[k], sr);
+                sd = __builtin_fma(c_tan_grid_weights.chk[q][k], dd[k], sd);
+            }
+            ok = ok && o && __builtin_fabs(sr - er) <= PXL_TG_TOL && __builtin_fabs(sd - ed) <= PXL_TG_TOL;
+        }
+        row_ok = ok;
+        double* nd = nodes[w][lane];
+#pragma unroll
+        for (int k = 0; k < PXL_TG_NODES; ++k) { nd[k] = dr[k]; nd[PXL_TG_NODES + k] = dd[k]; }
+        nd[2 * PXL_TG_NODES] = ra_a; nd[2 * PXL_TG_NODES + 1] = dec_a;
+    }
+    const unsigned long long okmask = __ballot(row_ok);
+    // the LDS writes above are this wave's own: a wave-level wait orders them before its reads below
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    // ---- phase B: lane = two adjacent columns
+    const int64_t i = ti0 + 2 * lane;
+    if (i >= nx) return;
+    const bool two = i + 1 < nx;
+    double wk[2][PXL_TG_NODES];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int k = 0; k < PXL_TG_NODES; ++k) wk[e][k] = c_tan_grid_weights.w[2 * lane + e][k];
+    const double X0 = (t.cpx - (double)(i + 1)) * t.uos, X1 = (t.cpx - (double)(i + 2)) * t.uos;
+#pragma unroll 1
+    for (int r = 0; r < nr; ++r) {
+        double a[2], d[2];
+        if ((okmask >> r) & 1ull) {
+            const double* nd = nodes[w][r];
+            double s0 = 0.0, s1 = 0.0, u0 = 0.0, u1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < PXL_TG_NODES; ++k) {
+                const double vr = nd[k], vd = nd[PXL_TG_NODES + k];
+                s0 = __builtin_fma(wk[0][k], vr, s0); s1 = __builtin_fma(wk[1][k], vr, s1);
+                u0 = __builtin_fma(wk[0][k], vd, u0); u1 = __builtin_fma(wk[1][k], vd, u1);
+            }
+            const double ra_a = nd[2 * PXL_TG_NODES], dec_a = nd[2 * PXL_TG_NODES + 1];
+            a[0] = ra_a + s0; a[1] = ra_a + s1; d[0] = dec_a + u0; d[1] = dec_a + u1;
+        } else {
+            const TanRow rw = tan_row(t, (double)(row0 + tj0 + r + 1));
+            tan_pix2sky_xrow<true>(t, rw, X0, X0 * X0, &a[0], &d[0]);
+            tan_pix2sky_xrow<true>(t, rw, X1, X1 * X1, &a[1], &d[1]);
+        }
+        const int64_t o = (tj0 + r) * nx + i;
+        if (VEC && two) {
+            *reinterpret_cast<double2*>(ra + o) = make_double2(a[0], a[1]);
+            *reinterpret_cast<double2*>(dec + o) = make_double2(d[0], d[1]);
+        } else {
+            ra[o] = a[0]; dec[o] = d[0];
+            if (two) { ra[o + 1] = a[1]; dec[o + 1] = d[1]; }
+        }
+    }
+}

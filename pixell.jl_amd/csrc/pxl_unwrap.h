@@ -408,6 +408,197 @@ __global__ __launch_bounds__(64) void k_unwind_apply(SRC src, typename SRC::raw_
 }
 
 // ------------------------------------------------------------------------------------------------
+// ONE-PASS form (round 4): the same verified integer scan with the carry between wave chunks handed over INSIDE the launch
+// (decoupled look-back), so the input is read once and the exact rewind is evaluated once: 32 B per 2xN point and ~125 VALU
+// instructions instead of 48 B and ~215 for k_unwind_sums + k_unwind_apply (profiles/r04_unwind_counters.txt).  Out-of-place
+// calls only: a chunk needs the element just before it as the caller gave it, and the fallback needs the whole input untouched.
+//
+// One workgroup per chunk (PXL_UW1_WAVES waves of 64 * PXL_UW1_U points each); the rewound values stay in registers between the sum and the apply step.
+//   1. chunk id = a ticket (atomic counter): every chunk with a smaller id has STARTED, and a started chunk publishes its
+//      aggregate before it waits for anything -- no wave ever waits for a wave that has not been dispatched
+//   2. m, the nominal increments, their sum T (per coordinate row) and "a NaN in this chunk"       -> link.agg
+//   3. look-back: lanes read the 64 links before the chunk; up to the nearest one that already carries an inclusive prefix they
+//      add aggregates; if an aggregate is still missing the wave polls again; a window without a prefix moves 64 links further
+//   4. inclusive prefix = exclusive + T                                                           -> link.pre0, link.pre1
+//   5. r_k, the check of every element against the reference's recurrence, y = m - r P + ref: the arithmetic of k_unwind_apply
+// A link field is ONE naturally aligned 8-byte {payload, tag} written by one agent-scope relaxed store (global_store_dwordx2 sc1)
+// and read by agent-scope relaxed loads (sc1: served by the L2, never by a stale L1): data and "ready" arrive together, so no
+// fence and no ordering between fields is needed (MI355X_MICROARCH.md, inter-workgroup visibility, form R2).  The links are
+// zeroed by a memset before the launch (tag 0 = not there yet).  A wave that polls 2^22 times without progress raises the
+// failure flag and publishes what it has, so every wave ends whatever happens; the flag sends the call to the fallback.
+// ------------------------------------------------------------------------------------------------
+#ifndef PXL_UW1_U
+#define PXL_UW1_U 8
+#endif
+struct UwLink { unsigned long long agg, pre0, pre1, pad; };          // 32 bytes per chunk
+
+__device__ inline void uw_publish(unsigned long long* p, unsigned int payload, unsigned int tag) {
+    __hip_atomic_store(p, ((unsigned long long)payload << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline unsigned long long uw_peek(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// PXL_UW1_WAVES waves of a workgroup share one chunk (64 * PXL_UW1_U points each, back to back) and ONE link: their sums meet in LDS
+// and only wave 0 walks the links.  (A first version gave every wave its own link: 195 000 links for 1e8 points, 5 000 of them
+// resident at once, and a wave that starts with all its predecessors still computing walks back through dozens of 64-link
+// windows -- 2.4 ms against the two-pass form's 1.05; profiles/r04_unwind_onepass.txt.  With 8 waves per link there are 16 times
+// fewer links, ~500 resident, and a look-back is a handful of windows.)
+#ifndef PXL_UW1_WAVES
+#define PXL_UW1_WAVES 8
+#endif
+template <class SRC>
+__global__ __launch_bounds__(64 * PXL_UW1_WAVES) void k_unwind_onepass(SRC src, typename SRC::raw_t* out, int64_t n, UwLink* __restrict__ links,
+                                                                       unsigned int* __restrict__ ticket, int32_t* __restrict__ flag) {
+    constexpr int U = PXL_UW1_U, NROW = SRC::NROW, NW = PXL_UW1_WAVES;
+    __shared__ unsigned int id_s;
+    __shared__ int wsum_s[2][NW], wnan_s[NW];
+    __shared__ int excl_s[2];
+    __shared__ unsigned int nanb_s, gaveup_s;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) { id_s = atomicAdd(ticket, 1u); gaveup_s = 0u; }
+    __syncthreads();
+    const int64_t id = (int64_t)id_s;
+    const int64_t base = (id * NW + wave) * 64 * U;
+    const double P = src.period, rP = src.rperiod, ref = src.ref;
+    typename SRC::raw_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t k = base + (int64_t)u * 64 + lane;
+        v[u] = (k < n) ? src.load(k) : src.zero();
+    }
+    double mfirst[2];
+    src.to_m((base > 0 && base - 1 < n) ? src.load(base - 1) : src.zero(), mfirst);
+    double mlast[2] = {mfirst[0], mfirst[1]};
+    double m[U][2];
+    int cc[U];                                      // (c0 + 1) | (c1 + 1) << 16: the two rows' increments as the wave scan takes them
+    int sum[2] = {0, 0};
+    bool nanl[2] = {false, false};
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t k = base + (int64_t)u * 64 + lane;
+        double mp[2];
+        int c[2] = {0, 0};
+        uw_element(src, lane, k, k < n, v[u], mlast, m[u], mp, c);
+        cc[u] = (c[0] + 1) | (NROW == 2 ? (c[1] + 1) << 16 : 0);
+#pragma unroll
+        for (int r = 0; r < NROW; ++r) {
+            sum[r] += c[r];
+            nanl[r] = nanl[r] || (k < n && m[u][r] != m[u][r]);
+            mlast[r] = uw_lane63(m[u][r]);
+        }
+    }
+    {
+        int T0 = uw_wave_total(sum[0]), T1 = NROW == 2 ? uw_wave_total(sum[1]) : 0;
+        unsigned int nh = (__ballot(nanl[0]) != 0ull ? 1u : 0u) | (NROW == 2 && __ballot(nanl[1]) != 0ull ? 2u : 0u);
+        if (lane == 0) { wsum_s[0][wave] = T0; wsum_s[1][wave] = T1; wnan_s[wave] = (int)nh; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        int T[2] = {0, 0};
+        unsigned int nan_here = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) { T[0] += wsum_s[0][w2]; T[1] += wsum_s[1][w2]; nan_here |= (unsigned)wnan_s[w2]; }
+        // 2. the aggregate: |T| <= 64 U NW = 4096 fits 14 bits with its offset
+        if (lane == 0) uw_publish(&links[id].agg, (unsigned)(T[0] + 8192) | ((unsigned)(T[1] + 8192) << 14) | (nan_here << 28), 1u);
+        // 3. look-back
+        int E[2] = {0, 0};
+        unsigned int nan_before = 0;
+        bool gave_up = false;
+        if (id > 0) {
+            int64_t top = id - 1;
+            unsigned int polls = 0;
+            for (;;) {
+                const int64_t j = top - lane;
+                unsigned long long a = 0, p0 = 0, p1 = 0;
+                if (j >= 0) {
+                    p0 = uw_peek(&links[j].pre0);
+                    p1 = NROW == 2 ? uw_peek(&links[j].pre1) : p0;
+                    a = uw_peek(&links[j].agg);
+                }
+                // chunks before the first one: an inclusive prefix of zero
+                const bool hasP = j < 0 || (((unsigned)p0 & 1u) && ((unsigned)p1 & 1u));
+                const bool hasA = j < 0 || ((unsigned)a & 1u);
+                const unsigned long long pmask = __ballot(hasP), amask = __ballot(hasA);
+                const int first = pmask ? __builtin_ctzll(pmask) : 64;          // nearest link with a prefix
+                const unsigned long long need = first >= 64 ? ~0ull : ((1ull << first) - 1ull);
+                if ((amask & need) != need) {                                    // an aggregate in between is not there yet
+                    if (++polls > (1u << 22)) { gave_up = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                int c0 = 0, c1 = 0;
+                unsigned int nb = 0;
+                if (j >= 0 && lane < first) {
+                    const unsigned int pa = (unsigned)(a >> 32);
+                    c0 = (int)(pa & 0x3fffu) - 8192; c1 = (int)((pa >> 14) & 0x3fffu) - 8192; nb = pa >> 28;
+                } else if (j >= 0 && lane == first) {
+                    c0 = (int)(unsigned)(p0 >> 32); c1 = (int)(unsigned)(p1 >> 32);
+                    nb = (((unsigned)p0 >> 1) & 1u) | ((((unsigned)p1 >> 1) & 1u) << 1);
+                }
+                E[0] += uw_wave_total(c0);
+                if (NROW == 2) E[1] += uw_wave_total(c1);
+                if (__ballot(nb & 1u) != 0ull) nan_before |= 1u;
+                if (__ballot(nb & 2u) != 0ull) nan_before |= 2u;
+                if (first < 64) break;
+                top -= 64;
+                polls = 0;
+            }
+        }
+        // 4. the inclusive prefix (tag bit 1: a NaN in this row up to and including this chunk)
+        if (lane == 0) {
+            const unsigned int nn = nan_before | nan_here;
+            uw_publish(&links[id].pre0, (unsigned)(E[0] + T[0]), 1u | ((nn & 1u) << 1));
+            if (NROW == 2) uw_publish(&links[id].pre1, (unsigned)(E[1] + T[1]), 1u | (((nn >> 1) & 1u) << 1));
+            excl_s[0] = E[0]; excl_s[1] = E[1]; nanb_s = nan_before; gaveup_s = gave_up ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    // 5. apply: k_unwind_apply's arithmetic on the values kept in registers
+    int carry[2] = {excl_s[0], excl_s[1]};
+    unsigned int nan_before = nanb_s;
+    for (int w2 = 0; w2 < wave; ++w2) { carry[0] += wsum_s[0][w2]; carry[1] += wsum_s[1][w2]; nan_before |= (unsigned)wnan_s[w2]; }
+    bool pex[2] = {(nan_before & 1u) != 0, (nan_before & 2u) != 0};
+    bool bad = gaveup_s != 0u;
+    mlast[0] = mfirst[0]; mlast[1] = mfirst[1];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t k = base + (int64_t)u * 64 + lane;
+        const bool valid = k < n;
+        const int s = uw_scan64(cc[u]);
+        const int tot = __builtin_amdgcn_readlane(s, 63);
+        double y[2] = {0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < NROW; ++r) {
+            const double mp = uw_shr1_first(m[u][r], mlast[r]);
+            mlast[r] = uw_lane63(m[u][r]);
+            const int field = r == 0 ? (s & 0xffff) : (s >> 16);
+            const int c = (r == 0 ? (cc[u] & 0xffff) : (cc[u] >> 16)) - 1;
+            const int rr = carry[r] + field - (lane + 1);            // r_k
+            carry[r] += (r == 0 ? (tot & 0xffff) : (tot >> 16)) - 64;
+            const unsigned long long nanmask = __ballot(valid && m[u][r] != m[u][r]);
+            const bool poisoned = pex[r] || (nanmask & ((2ull << lane) - 1ull)) != 0ull;
+            pex[r] = pex[r] || nanmask != 0ull;
+            if (!valid) continue;
+            if (poisoned) { y[r] = __builtin_nan("") + ref; continue; }
+            if (k > 0) {
+                const double yprev = mp - (double)(rr - c) * P;       // y[k-1] as the reference forms it
+                const double a = m[u][r] - yprev;
+                const double qa = a * rP;
+                if (!(fabs(qa - (double)rr) < 0.4999)) {
+                    const double q = a / P;
+                    if (!(rint(q) == (double)rr)) bad = true;
+                }
+            }
+            y[r] = (m[u][r] - (double)(k > 0 ? rr : 0) * P) + ref;     // k = 0: m - 0 = m, bit for bit
+        }
+        if (valid) SRC::store(out, k, y);
+    }
+    if (__any(bad) && lane == 0) atomicOr(flag, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Small batches: the whole of unwind! in ONE launch of one 1024-thread block, no scratch, no follow-up launches
 // (a catalogue of a few thousand positions is launch-bound: the multi-kernel form costs ~60 us of dispatches, the
 // serial kernel 94 ns per point; one CU needs ~9 us per 4096-point round and pass, so this wins up to 8192 points).  The block sweeps rounds of 16 wave chunks of 64*PXL_UWB_U points; chunk sums,

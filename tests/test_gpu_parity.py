@@ -518,6 +518,33 @@ def test_unwind_long_batches_bit_exact(pj, O, dev, n):
     assert bits_equal(got, O.pix2sky(g[1], jumps, O.WRAP_UNWIND))
 
 
+def test_unwind_one_pass_equals_two_pass(pj, O, dev):
+    """Out-of-place pix2sky!(safe=true) on a long batch takes the one-pass kernel (decoupled look-back between 512-point wave
+    chunks, k_unwind_onepass); the in-place call keeps the sums -> scan -> apply form.  Same arithmetic per element: the two
+    must agree bit for bit with each other and with the oracle's serial recurrence -- on a walk that wraps all the time (carries
+    of thousands of periods cross every chunk boundary), with the batch length not a multiple of anything, with a NaN late in one
+    row (everything after it is NaN, nothing before it changes) and with a half-period tie in the middle (the verification fails
+    and the fallback produces the answer)."""
+    g = _identity_wcs(pj)
+    n = 3_000_017
+    rng = np.random.default_rng(4)
+    walk = np.cumsum(rng.normal(0.3, 2.5, (n, 2)), axis=0)
+    cases = {"walk": walk}
+    w2 = walk.copy()
+    w2[2_500_003, 1] = float("nan")
+    cases["late NaN"] = w2
+    w3 = walk.copy()
+    w3[1_500_000:, 0] = w3[1_499_999, 0] + math.pi * np.arange(1, n - 1_500_000 + 1)      # exact half-period steps from there on
+    cases["ties"] = w3
+    for name, a in cases.items():
+        exp = O.pix2sky(g[1], a, O.WRAP_UNWIND)
+        d = to_dev(a, dev)
+        one = pj.pix2sky_(g, d, torch.empty_like(d), safe=True).cpu().numpy()        # out of place: one pass
+        two = pj.pix2sky_(g, d, d, safe=True).cpu().numpy()                          # in place: two passes
+        assert _same_bits_or_nan(one, exp), name
+        assert _same_bits_or_nan(two, exp), name
+
+
 def test_unwind_ties_and_nonfinite(pj, O, dev):
     """Adversarial inputs: steps of exactly half a period (rint ties-to-even decides), and NaN/Inf, which in
     the sequential recurrence poison every later element -- the verified scan must hand those to the serial
