@@ -291,7 +291,7 @@ def load_traffic(workload):
     return None
 
 
-def measure_traffic(workload, timeout_s=90):
+def measure_traffic(workload, timeout_s=90, kernel="k_reproject_dma", child_env=None, raw=False):
     """HBM bytes per launch of k_reproject_dma measured NOW: two child runs of this script under
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, the program directly after `--`, as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes; KiB -> bytes; FETCH_SIZE doubled on gfx950).  The caller has released its
@@ -315,6 +315,7 @@ def measure_traffic(workload, timeout_s=90):
                    "--workload", workload, "--steps", "3", "--warmup", "1", "--sustain-seconds", "0", "--no-cpu-baseline", "--no-configs",
                    "--no-traffic"]
             env = dict(os.environ, TMPDIR=tmp)
+            env.update(child_env or {})
             try:
                 r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
             except subprocess.TimeoutExpired:
@@ -322,12 +323,15 @@ def measure_traffic(workload, timeout_s=90):
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, (r.stderr or "").strip().splitlines()[-1:] or "")
-            vals = sorted(float(row["Counter_Value"]) for row in csv.DictReader(open(files[0])) if "k_reproject_dma" in row["Kernel_Name"])
+            vals = sorted(float(row["Counter_Value"]) for row in csv.DictReader(open(files[0])) if kernel in row["Kernel_Name"])
             if not vals:
-                return None, "no k_reproject_dma rows in the %s pass" % counter
+                return None, "no %s rows in the %s pass" % (kernel, counter)
             out[counter] = (vals[len(vals) // 2], len(vals))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    if raw:        # the caller applies the corrections that fit its access pattern
+        return None, {"fetch_counter_bytes": out["FETCH_SIZE"][0] * 1024.0, "write_bytes": out["WRITE_SIZE"][0] * 1024.0,
+                      "launches_sampled": [out["FETCH_SIZE"][1], out["WRITE_SIZE"][1]]}
     fetch = 2.0 * out["FETCH_SIZE"][0] * 1024.0
     write = out["WRITE_SIZE"][0] * 1024.0
     return fetch + write, {"fetch_bytes_x2": fetch, "write_bytes": write, "launches_sampled": [out["FETCH_SIZE"][1], out["WRITE_SIZE"][1]]}
@@ -881,6 +885,25 @@ def side_measurements(args, dev, result):
     torch.cuda.empty_cache()
     r = bench_scattered(a, 0, 1, dev)
     cfgs["cfg5"] = scattered_record(r, a.steps)
+    if not args.no_traffic:
+        # config 5's traffic, measured like the headline's (two rocprofv3 --pmc child passes) on 1e8 points of the same map: the
+        # taps are random 16-byte pairs inside one 64-byte sector, for which FETCH_SIZE (64 B per fabric request) is EXACT; the
+        # coordinate stream is a wide coalesced read that the counter tallies at half (the x2 rule of the guide), so half of
+        # its 16 B per point is added back; the 8-B-per-point output stream is written with 8-byte stores (WRITE_SIZE as read)
+        torch.cuda.empty_cache()
+        npts = 1e8
+        _tb, det = measure_traffic("cfg5", timeout_s=120, kernel="k_sample_pairs", raw=True,
+                                   child_env={"PXL_BENCH_POINTS": "%g" % npts, "PXL_BENCH_SAMPLER": "pairs"})
+        if isinstance(det, dict):
+            corrected = det["fetch_counter_bytes"] + 8.0 * npts + det["write_bytes"]
+            cfgs["cfg5"]["traffic"] = {"bytes_per_point": round(corrected / npts, 1), "fetch_counter_bytes_per_point": round(det["fetch_counter_bytes"] / npts, 1),
+                                       "write_bytes_per_point": round(det["write_bytes"] / npts, 1), "algorithmic_bytes_per_point": 56.0,
+                                       "sector_granular_bytes_per_point": 16 + 64 + 8, "points": npts, "launches_sampled": det["launches_sampled"],
+                                       "correction": "FETCH_SIZE as read for the random sector reads (exact) + 8 B/point for the coalesced coordinate stream it tallies at half; WRITE_SIZE as read",
+                                       "kernel": "k_sample_pairs (the row-pair copy is built outside this kernel: k_build_rowpairs streams the map once per rebuild)"}
+        else:
+            cfgs["cfg5"]["traffic"] = None
+            cfgs["cfg5"]["traffic_note"] = "live measurement failed: %s" % (det,)
     torch.cuda.empty_cache()
     result["configs"] = cfgs
     result["evaluators"] = gpu_evaluators(dev)

@@ -298,6 +298,26 @@ typedef struct pxl_mem_pair {
 int pxl_mem_pair_alloc(uint64_t src_bytes, uint64_t dst_bytes, uint64_t headroom_bytes, pxl_mem_pair* out, void* stream);
 int pxl_mem_pair_free(pxl_mem_pair* pair);
 
+/* The library's DEFAULT allocation policy for a map-sized output (round 4; the reference's seam: `similar` keeps the array type,
+ * src/enmap.jl:60-62, so a device host allocates its outputs through its own allocator -- this one).  ONE buffer of `bytes`
+ * bytes that lies in TWO memory classes, with NO head-room kept: the buffer is allocated on its own (hipMalloc), its 1 GiB
+ * windows are labelled with the probe above, and while it lies inside one class it is held as ballast and the next allocation
+ * is tried (consecutive allocations walk through the device's memory; a class run is 4-32 GiB long).  A candidate with at least
+ * 40 % of its windows in a second class is taken at once; otherwise the best one seen within `budget_bytes` of ballast (0 = 96
+ * GiB; never more than the free memory less 8 GiB) and 24 tries.  All ballast is freed before the call returns.  Buffers
+ * below 3 GiB are plain allocations.  The same fixed rule as pixell.jl_amd/placement.py::empty_map (what pj.reproject allocates
+ * its output with); topology discovery only, nothing about the caller's kernel is timed.  Contents unspecified (probed windows
+ * hold zeros).  Free with pxl_mem_free.  Uses the current device; synchronises `stream`.                                       */
+typedef struct pxl_mem_placed_info {
+    int32_t tries;             /* allocations made */
+    int32_t probes;            /* probe launches spent */
+    int32_t two_classes;       /* 1: at least 20 % of the buffer's windows lie in a second class */
+    int32_t minor_share_pct;   /* share of the buffer's windows outside its majority class, in percent */
+    uint64_t ballast_bytes;    /* largest amount of rejected candidates held at once (all freed on return) */
+} pxl_mem_placed_info;
+int pxl_mem_alloc_placed(uint64_t bytes, uint64_t budget_bytes, void** out, pxl_mem_placed_info* info, void* stream);
+int pxl_mem_free(void* ptr);
+
 /* ---- synthetic inputs (benchmark plumbing, deterministic counter-based generator):
  *      fill n doubles with N(0,1) (kind 0) or U[0,1) (kind 1) from splitmix64(seed, index+offset);
  *      uniform-on-sphere points (ra = 2pi*u1 - pi, dec = asin(2*u2 - 1)) as a 2xN batch.             */

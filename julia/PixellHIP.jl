@@ -39,17 +39,38 @@ function check(rc::Cint)
     error("libpixell_hip ($rc): " * unsafe_string(pointer(buf)))     # the reference raises exceptions too
 end
 
+# ---- the library's allocation policy for device arrays (include/pixell_hip.h: pxl_mem_alloc_placed)
+struct MemPlacedInfo                    # == struct pxl_mem_placed_info
+    tries::Int32
+    probes::Int32
+    two_classes::Int32
+    minor_share_pct::Int32
+    ballast_bytes::UInt64
+end
+const ALLOC_POLICY = Ref{Symbol}(:class_aware)          # or :plain
+
 # ---- minimal device array (column-major, like Array): the `AA` slot of Enmap{T,N,AA,W} (enmap.jl:10)
 mutable struct HIPArray{T,N} <: AbstractArray{T,N}
     ptr::Ptr{T}
     dims::NTuple{N,Int}
     parent::Any
+    # Every fresh device array -- `similar` (enmap.jl:60-62 keeps the array type), the outputs of reproject / pix2sky / posmap --
+    # comes from the library's allocation policy (pxl_mem_alloc_placed): below 3 GiB a plain hipMalloc; a map-sized buffer is
+    # looked for across a boundary between two of the HBM's memory classes, where the reprojection's write fronts store 15 %
+    # faster, and nothing but the buffer stays allocated afterwards.  ALLOC_POLICY[] = :plain turns that off.
     function HIPArray{T,N}(::UndefInitializer, dims::NTuple{N,Int}) where {T,N}
-        p = Ref{Ptr{Cvoid}}()
-        rc = ccall((:hipMalloc, libhip), Cint, (Ptr{Ptr{Cvoid}}, Csize_t), p, prod(dims) * sizeof(T))
-        rc == 0 || error("hipMalloc failed ($rc)")
+        p = Ref{Ptr{Cvoid}}(C_NULL)
+        nbytes = max(prod(dims) * sizeof(T), 1)
+        if ALLOC_POLICY[] === :plain
+            rc = ccall((:hipMalloc, libhip), Cint, (Ptr{Ptr{Cvoid}}, Csize_t), p, nbytes)
+            rc == 0 || error("hipMalloc failed ($rc)")
+        else
+            info = Ref(MemPlacedInfo(0, 0, 0, 0, 0))
+            check(ccall((:pxl_mem_alloc_placed, libpixell_hip), Cint, (UInt64, UInt64, Ptr{Ptr{Cvoid}}, Ref{MemPlacedInfo}, Ptr{Cvoid}),
+                        nbytes, 0, p, info, C_NULL))
+        end
         a = new{T,N}(Ptr{T}(p[]), dims, nothing)
-        finalizer(x -> ccall((:hipFree, libhip), Cint, (Ptr{Cvoid},), x.ptr), a)
+        finalizer(x -> ccall((:pxl_mem_free, libpixell_hip), Cint, (Ptr{Cvoid},), x.ptr), a)      # hipFree either way
     end
     # a view into `parent`'s memory (kept alive by the reference; no finalizer of its own): place_pair below
     HIPArray{T,N}(ptr::Ptr{T}, dims::NTuple{N,Int}, parent) where {T,N} = new{T,N}(ptr, dims, parent)
@@ -507,7 +528,7 @@ function place_pair(::Type{T}, src_dims::NTuple{N,Int}, dst_dims::NTuple{M,Int};
     return src, dst
 end
 
-export mem_probe_pair, map_classes, place_pair, place_pair_native, MemPair
+export mem_probe_pair, map_classes, place_pair, place_pair_native, MemPair, MemPlacedInfo, ALLOC_POLICY
 export HIPArray, posmap_device, reproject, reproject_generic, reproject!, ReprojectPlan, sample_bilinear, SamplePairs, HaloXfer, sharded_step!
 export PxlComm, comm_unique_id, comm_init_rank, comm_destroy, comm_backend
 end # module

@@ -80,6 +80,8 @@ SIGNATURES = {
     "pxl_mem_probe_pair": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_float), _P]),
     "pxl_mem_pair_alloc": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, _P, _P]),
     "pxl_mem_pair_free": (C.c_int, [_P]),
+    "pxl_mem_alloc_placed": (C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(_P), _P, _P]),
+    "pxl_mem_free": (C.c_int, [_P]),
     "pxl_fill_random_f64": (C.c_int, [_P, _I64, C.c_uint64, C.c_uint64, C.c_int, _P]),
     "pxl_fill_sphere_points_f64": (C.c_int, [_P, _I64, C.c_uint64, C.c_uint64, _P]),
 }
@@ -90,6 +92,12 @@ class MemPair(C.Structure):
                 ("arena_bytes", C.c_uint64), ("src_offset", C.c_uint64), ("dst_offset", C.c_uint64),
                 ("classes", C.c_int32), ("dst_two_classes", C.c_int32), ("src_own_class", C.c_int32), ("probes", C.c_int32),
                 ("separate_tried", C.c_int32), ("reserved_", C.c_int32)]
+
+
+class MemPlacedInfo(C.Structure):
+    """struct pxl_mem_placed_info (include/pixell_hip.h)."""
+    _fields_ = [("tries", C.c_int32), ("probes", C.c_int32), ("two_classes", C.c_int32), ("minor_share_pct", C.c_int32),
+                ("ballast_bytes", C.c_uint64)]
 
 
 _lib = None

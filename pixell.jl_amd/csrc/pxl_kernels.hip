@@ -592,10 +592,13 @@ int pxl_posmap_tan_f64(const pxl_car_wcs* wcs, const int64_t shape[2], int64_t r
     const bool grid_pays = fabs(tp0.uos) * PXL_TG_W <= 0.04 && fabs(tp0.cd0) >= 0.3;
     if (env_int("PXL_TAN_GRID", grid_pays ? 1 : 0) && shape[0] >= PXL_TG_W && nrows >= 8) {
         const int64_t ntx = (shape[0] + PXL_TG_W - 1) / PXL_TG_W, nty = (nrows + PXL_TG_ROWS - 1) / PXL_TG_ROWS;
-        const int64_t nblk = (ntx * nty + 3) / 4;
+        int fronts = env_int("PXL_POSMAP_FRONTS", 8);
+        if (fronts < 1 || nty < 4 * fronts) fronts = 1;
+        const int64_t per = (nty + fronts - 1) / fronts, nbx = (ntx + 3) / 4;
+        const int64_t nblk = per * fronts * nbx;
         if (nblk <= 0x7fffffffLL) {
-            if (vec) hipLaunchKernelGGL((k_posmap_tan_grid<true>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, tan_setup(*wcs), shape[0], row0, nrows, ntx, ra, dec);
-            else     hipLaunchKernelGGL((k_posmap_tan_grid<false>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, tan_setup(*wcs), shape[0], row0, nrows, ntx, ra, dec);
+            if (vec) hipLaunchKernelGGL((k_posmap_tan_grid<true>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, tp0, shape[0], row0, nrows, ntx, per, fronts, ra, dec);
+            else     hipLaunchKernelGGL((k_posmap_tan_grid<false>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, tp0, shape[0], row0, nrows, ntx, per, fronts, ra, dec);
             return check_launch("k_posmap_tan_grid");
         }
     }
@@ -1095,15 +1098,22 @@ int pxl_reproject_car_bilinear_f64(const pxl_car_wcs* wcs_in, const int64_t shap
 }
 
 // diagnostics of the tiled generic reprojection: how many 128 x 32 tiles of the last call took the exact path
+// Two slots used alternately: a call counts in one, and its last launch zeroes the other for the next call (no memset per call).
 static unsigned int* g_exact_tiles[64] = {};
+static int g_exact_slot[64] = {};
 static int64_t g_generic_tiles[64] = {};
-static unsigned int* exact_tiles_counter(int* dev_out) {
+static unsigned int* exact_tiles_counter(int* dev_out, bool advance = false) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     *dev_out = dev;
     std::lock_guard<std::mutex> lock(g_pool_mu);
-    if (!g_exact_tiles[dev] && hipMalloc((void**)&g_exact_tiles[dev], 64) != hipSuccess) { (void)hipGetLastError(); g_exact_tiles[dev] = nullptr; }
-    return g_exact_tiles[dev];
+    if (!g_exact_tiles[dev]) {
+        if (hipMalloc((void**)&g_exact_tiles[dev], 64) != hipSuccess || hipMemset(g_exact_tiles[dev], 0, 64) != hipSuccess) {
+            (void)hipGetLastError(); g_exact_tiles[dev] = nullptr; return nullptr;
+        }
+    }
+    if (advance) g_exact_slot[dev] ^= 1;
+    return g_exact_tiles[dev] + g_exact_slot[dev];
 }
 
 int pxl_reproject_generic_last_tiles(int64_t* exact_tiles, int64_t* total_tiles, void* stream) {
@@ -1147,8 +1157,8 @@ int pxl_reproject_generic_bilinear_f64(const pxl_car_wcs* wcs_in, int proj_in, c
         return check_launch("k_reproject_generic");
     }
     int dev = 0;
-    p.exact_tiles = exact_tiles_counter(&dev);
-    if (p.exact_tiles) { HIP_TRY(hipMemsetAsync(p.exact_tiles, 0, 4, (hipStream_t)stream)); g_generic_tiles[dev] = gx * gy; }
+    p.exact_tiles = exact_tiles_counter(&dev, true);
+    if (p.exact_tiles) { p.exact_tiles_next = g_exact_tiles[dev] + (g_exact_slot[dev] ^ 1); g_generic_tiles[dev] = gx * gy; }
     // per-tile lattice (30 coordinate pairs) + flag from the library's stream-ordered scratch pool
     const int64_t ntiles = gx * gy;
     const size_t lat_bytes = (size_t)ntiles * (PXL_TNX * PXL_TNY) * sizeof(double2), total_bytes = lat_bytes + (size_t)ntiles * 4;
@@ -1167,7 +1177,7 @@ int pxl_reproject_generic_bilinear_f64(const pxl_car_wcs* wcs_in, int proj_in, c
         hipLaunchKernelGGL(k_reproject_generic_tiled, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, (const double2*)lat, (const int32_t*)flag);
     else
         hipLaunchKernelGGL(k_reproject_generic_tiled2, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, (const double2*)lat, (const int32_t*)flag);
-    hipLaunchKernelGGL(k_reproject_generic_exact_tiles, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, (const int32_t*)flag);
+    hipLaunchKernelGGL(k_reproject_generic_exact_tiles, dim3((unsigned)std::min<int64_t>(ntiles, 1024)), dim3(256), 0, st, p, (const int32_t*)flag, gx, ntiles);
     int rc = check_launch("k_reproject_generic_tiled");
     hipError_t fe = hipFreeAsync(ws, st);
     if (fe != hipSuccess && rc == PXL_OK) rc = fail(PXL_EHIP, "reproject_generic: hipFreeAsync: %s", hipGetErrorString(fe));

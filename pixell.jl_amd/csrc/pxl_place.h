@@ -171,3 +171,60 @@ int pxl_mem_pair_free(pxl_mem_pair* p) {
     if (e1 != hipSuccess || e2 != hipSuccess) return fail(PXL_EHIP, "mem_pair_free: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     return PXL_OK;
 }
+
+// ---- the default policy for ONE map-sized buffer: two classes, no head-room (include/pixell_hip.h)
+int pxl_mem_alloc_placed(uint64_t bytes, uint64_t budget_bytes, void** out, pxl_mem_placed_info* info, void* stream) {
+    using namespace pxl_place;
+    if (!out) return fail(PXL_EINVAL, "mem_alloc_placed: null result");
+    *out = nullptr;
+    if (info) memset(info, 0, sizeof *info);
+    if (bytes == 0) return fail(PXL_EINVAL, "mem_alloc_placed: empty buffer");
+    hipStream_t st = (hipStream_t)stream;
+    if (budget_bytes == 0) budget_bytes = 96 * GiB;
+    auto alloc = [&](char** p) -> int {
+        hipError_t e = hipMalloc((void**)p, bytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(PXL_EHIP, "mem_alloc_placed: hipMalloc of %.1f GiB: %s", bytes / (double)GiB, hipGetErrorString(e)); }
+        return PXL_OK;
+    };
+    char* best = nullptr;
+    int best_share = -1, tries = 0, probes = 0;
+    uint64_t held = 0, peak = 0;
+    std::vector<char*> ballast;
+    int rc = PXL_OK;
+    if (bytes < 3 * GiB) {
+        rc = alloc(&best);
+        if (rc) return rc;
+        best_share = 0; tries = 1;
+    }
+    while (bytes >= 3 * GiB) {
+        char* cand = nullptr;
+        rc = alloc(&cand);
+        if (rc) { if (best) { rc = PXL_OK; } break; }             // out of memory mid-search: keep the best so far
+        ++tries;
+        ClassMap cm;
+        rc = map_classes(cand, bytes, GiB, st, &cm);
+        if (rc) { (void)hipFree(cand); break; }
+        probes += cm.probes;
+        int cnt[64] = {0}, major = 0;
+        for (int l : cm.labels) { if (l >= 0 && l < 64 && ++cnt[l] > major) major = cnt[l]; }
+        const int share = cm.labels.empty() ? 0 : (int)(100 - 100 * (int64_t)major / (int64_t)cm.labels.size());
+        if (share > best_share) { if (best) { ballast.push_back(best); held += bytes; } best = cand; best_share = share; }
+        else { ballast.push_back(cand); held += bytes; }
+        peak = std::max(peak, held);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        if (best_share >= 40 || tries >= 24 || held + bytes > budget_bytes || free_b < bytes + 8 * GiB) break;
+    }
+    for (char* b : ballast) (void)hipFree(b);
+    if (rc) { if (best) (void)hipFree(best); return rc; }
+    *out = best;
+    if (info) { info->tries = tries; info->probes = probes; info->two_classes = best_share >= 20; info->minor_share_pct = best_share < 0 ? 0 : best_share; info->ballast_bytes = peak; }
+    return PXL_OK;
+}
+
+int pxl_mem_free(void* ptr) {
+    if (!ptr) return PXL_OK;
+    hipError_t e = hipFree(ptr);
+    if (e != hipSuccess) return fail(PXL_EHIP, "mem_free: %s", hipGetErrorString(e));
+    return PXL_OK;
+}

@@ -14,7 +14,8 @@ struct GenericParams {
     int32_t nc, periodic, proj_in, proj_out;
     CarAffine out_car; TanParams out_tan;
     Sky2Pix in_car; TanParams in_tan;
-    unsigned int* exact_tiles;         // diagnostics: counts the tiles that took the exact path (may be null)
+    unsigned int* exact_tiles;         // counts the tiles that took the exact path (may be null)
+    unsigned int* exact_tiles_next;    // the slot the NEXT call will count in: zeroed by this call's exact launch (no memset per call)
 };
 // exact source coordinates of output pixel (i, j) (1-based, may lie outside the output map): the evaluators of the
 // reference, per pixel.  *visible: the sky point is in front of a Gnomonic source's tangent plane.
@@ -215,17 +216,23 @@ __global__ __launch_bounds__(256) void k_generic_lattice(GenericParams p, int64_
 }
 // the tiles whose interpolant failed its check: exact evaluation per pixel (a launch of its own, so that the hot
 // kernel below carries no libm code; blocks of tiles that passed exit at once)
-__global__ __launch_bounds__(256) void k_reproject_generic_exact_tiles(GenericParams p, const int32_t* __restrict__ flag) {
-    const int64_t tile = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-    if (!flag[tile]) return;
-    const int64_t i = (int64_t)blockIdx.x * PXL_TW + (threadIdx.x & (PXL_TW - 1)), jr0 = (int64_t)blockIdx.y * PXL_TH + threadIdx.x / PXL_TW;
-    if (i >= p.nxo) return;
-    for (int q = 0; q < PXL_TH / PXL_TROWS; ++q) {
-        const int64_t jr = jr0 + PXL_TROWS * q;
-        if (jr < p.nyo) {
-            double x, y; bool visible;
-            generic_coords(p, (double)(i + 1), (double)(jr + 1), &x, &y, &visible);
-            generic_store(p, jr * p.nxo + i, x, y, visible);
+// A small fixed grid that walks the tiles: when no tile failed (the counter of the lattice launch is zero) every block leaves at
+// once -- 2 us instead of the 4.2 us that one (empty) block per tile cost on a 4096^2 patch.
+__global__ __launch_bounds__(256) void k_reproject_generic_exact_tiles(GenericParams p, const int32_t* __restrict__ flag, int64_t gx, int64_t ntiles) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.exact_tiles_next) *p.exact_tiles_next = 0u;
+    if (p.exact_tiles && *p.exact_tiles == 0u) return;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (!flag[tile]) continue;
+        const int64_t bx = tile % gx, by = tile / gx;
+        const int64_t i = bx * PXL_TW + (threadIdx.x & (PXL_TW - 1)), jr0 = by * PXL_TH + threadIdx.x / PXL_TW;
+        if (i >= p.nxo) continue;
+        for (int q = 0; q < PXL_TH / PXL_TROWS; ++q) {
+            const int64_t jr = jr0 + PXL_TROWS * q;
+            if (jr < p.nyo) {
+                double x, y; bool visible;
+                generic_coords(p, (double)(i + 1), (double)(jr + 1), &x, &y, &visible);
+                generic_store(p, jr * p.nxo + i, x, y, visible);
+            }
         }
     }
 }

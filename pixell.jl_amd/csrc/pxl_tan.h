@@ -234,14 +234,19 @@ __device__ inline void tg_delta(const TanRow& rw, double D2, double N2, double X
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_posmap_tan_grid(TanParams t, int64_t nx, int64_t row0, int64_t nrows, int64_t ntx,
-                                                         double* __restrict__ ra, double* __restrict__ dec) {
+                                                         int64_t per, int fronts, double* __restrict__ ra, double* __restrict__ dec) {
     __shared__ __attribute__((aligned(16))) double nodes[4][PXL_TG_ROWS][2 * PXL_TG_NODES + 2];      // per wave and row: 9 dRA, 9 dDEC, RA_a, DEC_a
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t tile = (int64_t)blockIdx.x * 4 + w;
-    const int64_t tx = tile % ntx, ty = tile / ntx;
+    // EIGHT WRITE FRONTS, as in k_posmap_car (a write-only stream swept as one front takes 5.3 TB/s, dealt into eight parts of the
+    // map 5.9 and more): blocks b and b + 8 share an XCD, so block b works in part b % 8 of the map's tile rows.  `fronts` = 1
+    // for small maps (per = all the tile rows)
+    const int64_t nbx = (ntx + 3) / 4;                                           // blocks per tile row (4 tiles side by side)
+    const int64_t v = fronts > 1 ? (int64_t)(blockIdx.x % fronts) : 0, jb = fronts > 1 ? (int64_t)(blockIdx.x / fronts) : (int64_t)blockIdx.x;
+    const int64_t ty = v * per + jb / nbx, tx = (jb % nbx) * 4 + w;
+    if (jb / nbx >= per || tx >= ntx) return;                                   // (whole wave; no block-level barrier is used)
     const int64_t ti0 = tx * PXL_TG_W, tj0 = ty * PXL_TG_ROWS;                  // tile origin: 0-based column, row within the request
-    if (tj0 >= nrows) return;                                                   // (whole wave; no block-level barrier is used)
+    if (tj0 >= nrows) return;
     const int nr = (int)((nrows - tj0) < PXL_TG_ROWS ? (nrows - tj0) : PXL_TG_ROWS);
     const double h = (PXL_TG_W - 1.0) / (PXL_TG_NODES - 1);
     // ---- phase A: lane = row

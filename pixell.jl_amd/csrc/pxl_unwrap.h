@@ -428,7 +428,7 @@ __global__ __launch_bounds__(64) void k_unwind_apply(SRC src, typename SRC::raw_
 // failure flag and publishes what it has, so every wave ends whatever happens; the flag sends the call to the fallback.
 // ------------------------------------------------------------------------------------------------
 #ifndef PXL_UW1_U
-#define PXL_UW1_U 8
+#define PXL_UW1_U 4
 #endif
 struct UwLink { unsigned long long agg, pre0, pre1, pad; };          // 32 bytes per chunk
 
@@ -443,9 +443,11 @@ __device__ inline unsigned long long uw_peek(const unsigned long long* p) {
 // and only wave 0 walks the links.  (A first version gave every wave its own link: 195 000 links for 1e8 points, 5 000 of them
 // resident at once, and a wave that starts with all its predecessors still computing walks back through dozens of 64-link
 // windows -- 2.4 ms against the two-pass form's 1.05; profiles/r04_unwind_onepass.txt.  With 8 waves per link there are 16 times
-// fewer links, ~500 resident, and a look-back is a handful of windows.)
+// fewer links, ~500 resident, and a look-back is a handful of windows: 0.93 ms; 16 waves of 256 points each: 0.88 ms.  Letting ALL
+// waves of the workgroup look back at once -- 1 024 links per round, windows combined through LDS -- was built and measured SLOWER
+// (1.10 ms: sixteen times the polling traffic and two workgroup barriers per round) and removed.)
 #ifndef PXL_UW1_WAVES
-#define PXL_UW1_WAVES 8
+#define PXL_UW1_WAVES 16
 #endif
 template <class SRC>
 __global__ __launch_bounds__(64 * PXL_UW1_WAVES) void k_unwind_onepass(SRC src, typename SRC::raw_t* out, int64_t n, UwLink* __restrict__ links,

@@ -59,6 +59,7 @@ _JULIA_TO_C = {
     "Int64": {"int64_t"}, "UInt64": {"uint64_t"}, "Cint": {"int"}, "Cdouble": {"double"}, "Csize_t": {"size_t"},
     "Ptr{Cdouble}": {"double*"}, "Ptr{Cfloat}": {"float*"}, "Ptr{Int64}": {"int64_t*"},
     "Ptr{Cvoid}": {"void*", "pxl_reproject_plan*", "pxl_mem_pair*"},
+    "Ref{MemPlacedInfo}": {"pxl_mem_placed_info*"},
     "Ptr{Ptr{Cvoid}}": {"void**", "pxl_reproject_plan**"},
     "Ptr{UInt8}": {"char*", "void*"},
     "Ptr{HaloXfer}": {"pxl_halo_xfer*"},
@@ -151,6 +152,22 @@ def test_mem_pair_struct_mirrors(pj):
     jmap = {"void*": "Ptr{Cvoid}", "uint64_t": "UInt64", "int32_t": "Int32"}
     assert jfields == [(n, jmap[t]) for t, n in cfields]
     assert ctypes.sizeof(pj._lib.MemPair) == 4 * 8 + 3 * 8 + 6 * 4
+
+
+def test_mem_placed_info_struct_mirrors(pj):
+    """struct pxl_mem_placed_info (the default allocation policy's report): header, ctypes mirror and Julia mirror agree."""
+    header = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    body = re.search(r"typedef struct pxl_mem_placed_info \{(.*?)\}", header, flags=re.S).group(1)
+    cfields = [(t.replace(" ", ""), n) for t, n in re.findall(r"([\w \*]+?)\s*\b(\w+);", body)]
+    assert [n for _, n in cfields] == [n for n, _ in pj._lib.MemPlacedInfo._fields_]
+    cmap = {"uint64_t": ctypes.c_uint64, "int32_t": ctypes.c_int32}
+    assert [cmap[t] for t, _ in cfields] == [t for _, t in pj._lib.MemPlacedInfo._fields_]
+    text = open(os.path.join(ROOT, "julia", "PixellHIP.jl")).read()
+    jbody = re.search(r"struct MemPlacedInfo[^\n]*\n(.*?)\nend", text, flags=re.S).group(1)
+    jfields = re.findall(r"^\s*(\w+)::([\w{}]+)", jbody, flags=re.M)
+    jmap = {"uint64_t": "UInt64", "int32_t": "Int32"}
+    assert jfields == [(n, jmap[t]) for t, n in cfields]
+    assert ctypes.sizeof(pj._lib.MemPlacedInfo) == 4 * 4 + 8
 
 
 def test_struct_layout_matches_reference_wcs(pj):

@@ -223,3 +223,32 @@ def test_strip_reprojector_alloc_maps(pj, dev):
         lo_s, hi_s, lo_d, hi_d = src.data_ptr(), src.data_ptr() + src.numel() * 8, dst.data_ptr(), dst.data_ptr() + dst.numel() * 8
         assert hi_s <= lo_d or hi_d <= lo_s
         del src, dst, info
+
+
+def test_native_alloc_placed(pj, dev):
+    """pxl_mem_alloc_placed / pxl_mem_free: the default allocation policy through the C ABI (what the Julia HIPArray constructor
+    calls): a 4 GiB buffer comes back usable, with its report filled in and nothing else left allocated; small buffers are plain."""
+    import ctypes as C
+    lib = pj.load_library()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(dev)
+    ptr = C.c_void_p()
+    info = pj._lib.MemPlacedInfo()
+    nbytes = 4 << 30
+    pj._lib.check(lib.pxl_mem_alloc_placed(nbytes, 40 << 30, C.byref(ptr), C.byref(info), None))
+    assert ptr.value and ptr.value % 256 == 0
+    assert 1 <= info.tries <= 24 and 0 <= info.minor_share_pct <= 100 and info.two_classes in (0, 1)
+    assert info.ballast_bytes <= 40 << 30
+    free1, _ = torch.cuda.mem_get_info(dev)
+    assert free0 - free1 <= nbytes + (256 << 20), (free0 - free1, info.tries)        # the ballast is gone: only the buffer remains
+    # the memory is real: the probe writes to it
+    us = C.c_float()
+    pj._lib.check(lib.pxl_mem_probe_pair(ptr, C.c_void_p(ptr.value + (2 << 30)), 1 << 30, 1, C.byref(us), None))
+    assert us.value > 0
+    pj._lib.check(lib.pxl_mem_free(ptr))
+    small = C.c_void_p()
+    pj._lib.check(lib.pxl_mem_alloc_placed(1 << 20, 0, C.byref(small), C.byref(info), None))
+    assert small.value and info.tries == 1 and info.probes == 0
+    pj._lib.check(lib.pxl_mem_free(small))
+    assert lib.pxl_mem_alloc_placed(0, 0, C.byref(small), None, None) == -22
+    assert lib.pxl_mem_free(None) == 0
