@@ -22,10 +22,12 @@ Workloads (BASELINE.json configs; natural Clenshaw-Curtis shapes, ny = nx/2 + 1)
     cfg2: (4096, 2049) -> (8192, 4097) (Infinity-Cache resident; informational).
     cfg5: 1e9 scattered (ra, dec) points sampled from a (43200, 21601) map replicated per GPU.
 
-Where the maps live: by default they are placed by pj.place_pair (one allocation with head-room, the HBM's three memory classes
-mapped with the library's store probe, the destination across a class boundary -- DESIGN.md 9 item 6; a fixed rule, no timing of
-this workload, no candidates); --arena / --two-allocations give plain allocations, and the default run reports the plain first
-placement of every reprojection config beside the class-aware one.
+Where the maps live (round 4): as a caller of the drop-in API gets them -- the source in a plain torch allocation, the destination
+from the library's default allocation policy (pj.empty_map: a map of 3 GiB or more is looked for across a boundary between two of
+the HBM's memory classes with the library's store probe, no head-room kept).  --placed = pj.place_pair (one
+allocation with 144 GiB of head-room: the best placement, rounds 1-3's headline policy), --arena / --two-allocations = plain
+allocations; the default run reports all three for every reprojection config (configs.*.api_default / .class_aware_placement /
+.plain_first_placement).
 
 The default run (N = 1, workload cfg4) appends, after the headline and outside its timed region, a "configs" block
 with the other BASELINE configs measured in the same process (cfg2, cfg3, cfg3s, cfg5 at 1e9 points: ms per step,
@@ -241,6 +243,10 @@ def place_buffers(sh, candidates, dev, keep="first", arena=False):
                 pinfo = {"placement": "place_pair FAILED (%s): plain allocation, destination above the source" % type(e).__name__,
                          "allocation_GiB": None, "classes": None, "class_runs_label_from_to_GiB": None, "probe_us_same_class": None,
                          "probe_us_different_classes": None, "src_offset_GiB": None, "dst_offset_GiB": None, "source": None}
+        elif arena == "api":    # what a caller of the drop-in API gets: the source in a plain allocation, the output allocated by the
+            # library's default policy (placement.empty_map: two memory classes when a candidate turns up, no head-room kept)
+            src = sh.alloc_src()
+            dst, ainfo = pj.empty_map(sh.dst_tensor_shape(), device=dev)
         elif arena:       # one allocation, destination above the source (sharding.alloc_pair: a fixed policy, nothing probed)
             src, dst, hold = sh.alloc_pair()
             holds.append(hold)
@@ -263,7 +269,7 @@ def place_buffers(sh, candidates, dev, keep="first", arena=False):
         if best is None or (keep == "best" and t < best[2]):
             best = (src, dst, t)
         del src, dst
-        if arena != "placed":
+        if arena not in ("placed", "api"):
             holds.clear()
         if k + 1 < candidates:
             # return the losing blocks to the driver and perturb the heap so the next try lands elsewhere
@@ -276,6 +282,9 @@ def place_buffers(sh, candidates, dev, keep="first", arena=False):
     alloc_desc = ("one allocation, destination above the source (DecStripReprojector.alloc_pair: fixed policy, nothing probed)" if arena else "two allocations")
     if arena == "placed":
         alloc_desc = {"policy": "pj.place_pair: one allocation with head-room, memory classes mapped with pxl_mem_probe_pair, destination across a class boundary", **pinfo}
+    if arena == "api":
+        alloc_desc = {"policy": "the library's default (what pj.reproject / DecStripReprojector.alloc_maps / the Julia HIPArray constructor allocate with): source "
+                                "torch.empty, destination pj.empty_map -- class-aware, no head-room kept", **ainfo}
     return best[0], best[1], {"allocation": alloc_desc, "candidates_ms": tried,
                               "chosen_ms": round(best[2], 4), "chosen": keep,
                               "first_ms": tried[0], "median_ms": sorted(tried)[len(tried) // 2], "best_ms": min(tried)}
@@ -350,9 +359,14 @@ def main():
     ap.add_argument("--placements", type=int, default=int(os.environ.get("PXL_BENCH_PLACEMENTS", "1")),
                     help="buffer placements probed at setup (default 1: just the first allocation, which is what the "
                          "headline always reports unless --keep-placement best)")
+    ap.add_argument("--api-default", dest="arena", action="store_const", const="api",
+                    default={"1": True, "0": False, "placed": "placed"}.get(os.environ.get("PXL_BENCH_ARENA", "api"), "api"),
+                    help="(default since round 4) the maps as a caller of the drop-in API gets them: the source in a plain torch allocation, the "
+                         "destination from the library's default allocation policy (pj.empty_map: a map of 3 GiB or more is looked for across a "
+                         "boundary between two memory classes, rejected candidates are held only during the search, nothing but the map stays "
+                         "allocated).  The default run reports the 144-GiB-head-room placement (--placed) and the plain one beside it")
     ap.add_argument("--placed", dest="arena", action="store_const", const="placed",
-                    default={"1": True, "0": False}.get(os.environ.get("PXL_BENCH_ARENA", "placed"), "placed"),
-                    help="(default) class-aware placement of the maps, pj.place_pair: ONE allocation with 144 GiB of head-room, its three "
+                    help="class-aware placement of the maps with head-room, pj.place_pair: ONE allocation with 144 GiB of head-room, its three "
                          "memory classes mapped with the library's store probe (pxl_mem_probe_pair, ~100 probes of 0.3 ms), the destination "
                          "put across a class boundary, the source in a class it does not touch.  The reprojection's eight XCD write fronts "
                          "store at 6.8-7.1 TB/s split over two classes and at 5.8-6.0 TB/s inside one, which is where a plain allocation "
@@ -385,9 +399,9 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
-    if os.environ.get("PXL_BENCH_SHARE_GPU") and args.arena == "placed":
-        # rehearsal: several ranks on ONE device.  The class-aware placement takes an allocation with 144 GiB of head-room per rank,
-        # which ranks sharing a device would fight over; a rehearsal checks the flow, not the rate: plain allocations
+    if os.environ.get("PXL_BENCH_SHARE_GPU") and args.arena in ("placed", "api"):
+        # rehearsal: several ranks on ONE device.  The class-aware policies hold ballast / head-room while they look for a class
+        # boundary, which ranks sharing a device would fight over; a rehearsal checks the flow, not the rate: plain allocations
         args.arena = True
 
     # stdout carries exactly one JSON line: libraries (RCCL prints a version banner, gloo its connection notes) write
@@ -510,7 +524,9 @@ def bench_reproject(args, rank, world, dev):
     nx, ny, nc = shape_in
     nxo, nyo = shape_out
     sh = pj.DecStripReprojector(shape_in, wcs_in, shape_out, wcs_out, rank, world, dev)
-    src, dst, placement = place_buffers(sh, 1 if args.arena == "placed" else args.placements, dev, args.keep_placement, arena=args.arena)
+    if args.arena in ("placed", "api") and args.placements > 1:
+        print("bench.py: --placements %d is ignored with the %s allocation policy (one fixed rule, first and only allocation)" % (args.placements, args.arena), file=sys.stderr, flush=True)
+    src, dst, placement = place_buffers(sh, 1 if args.arena in ("placed", "api") else args.placements, dev, args.keep_placement, arena=args.arena)
     torch.cuda.synchronize(dev)
     # ---- choose the halo transport (N > 1).  Candidates in order: "native" = the library's own sharded step (RCCL
     # send/recv issued from C straight out of / into the resident buffer), "torch" = torch.distributed
@@ -854,8 +870,9 @@ def scattered_check(m, wcs, shape, sky, out, world, dev, npick=4096):
 def side_measurements(args, dev, result):
     """After the headline, outside its timed region (N = 1, default workload): the other BASELINE configs, the
     evaluators the reference has, and the CPU oracle's rates for them -- so that one driver-observed line carries
-    what used to live only in builder-kept files under profiles/.  Every reprojection config is measured twice: with the
-    class-aware placement the headline uses (pj.place_pair) and with a plain, unprobed first placement (alloc_pair)."""
+    what used to live only in builder-kept files under profiles/.  Every reprojection config is measured three ways: through the
+    drop-in API with the library allocating the output (api_default: the policy the headline uses too), with the 144-GiB-head-room
+    placement (pj.place_pair) and with a plain, unprobed first placement (alloc_pair)."""
     cfgs = {}
     for name in ("cfg2", "cfg3", "cfg3s", "cfg4"):
         a = argparse.Namespace(**vars(args))
@@ -866,7 +883,7 @@ def side_measurements(args, dev, result):
             r["note"] = "268 MB of output: Infinity-Cache resident, not roofline evidence (SURVEY 8(d)); plain allocation"
             cfgs[name] = r
             continue
-        if name == "cfg4" and args.arena == "placed":       # the headline IS the class-aware run of this config
+        if name == "cfg4" and args.arena == "placed":       # the headline IS the class-aware run of this config (only with --placed)
             placed = {"Mpix_s": result["value"], "ms_per_step": result["ms_per_step"], "kernel_ms_avg": result["roofline"]["kernel_ms_avg"],
                       "frac": result["roofline"]["frac"], "check": result["check"], "note": "the headline above"}
         else:
@@ -874,12 +891,14 @@ def side_measurements(args, dev, result):
             placed = variant(a, dev)
         a.arena = True
         plain = variant(a, dev)
+        api = api_default_record(name, dev)
+        # the record's own numbers are what the drop-in API delivers (api_default); the two other allocation policies beside it
         cfgs[name] = {"workload": plain.pop("workload"), "bytes_per_output_value": plain.pop("bytes_per_output_value"),
-                      "ms_per_step": placed["ms_per_step"], "kernel_ms_avg": placed["kernel_ms_avg"], "frac": placed["frac"],
-                      "check": placed["check"], "class_aware_placement": placed, "plain_first_placement": plain}
+                      "kernel_ms_avg": api["ms_per_call"], "frac": api["frac"], "check": api["check"],
+                      "numbers_are": "api_default: pj.reproject(m, shape_out, wcs_out) with the library allocating the output",
+                      "api_default": api, "class_aware_placement": placed, "plain_first_placement": plain}
         cfgs[name]["class_aware_placement"].pop("workload", None)
         cfgs[name]["class_aware_placement"].pop("bytes_per_output_value", None)
-        cfgs[name]["api_default"] = api_default_record(name, dev)
     a = argparse.Namespace(**vars(args))
     a.workload, a.steps, a.warmup = "cfg5", 6, 2
     torch.cuda.empty_cache()
@@ -935,6 +954,7 @@ def api_default_record(name, dev, steps=10, warmup=2):
     torch.cuda.synchronize(dev)
     first_s = time.perf_counter() - t0
     held = torch.cuda.memory_reserved(dev) - base_reserved
+    alloc_info = pj.last_allocation_info()
     pair = 8.0 * nc * (nx * ny + nxo * nyo)
     plan = pj.ReprojectPlan(m.shape, m.wcs, shape_out, wcs_out, device=dev)
     for _ in range(warmup):
@@ -954,7 +974,7 @@ def api_default_record(name, dev, steps=10, warmup=2):
            "ms_per_call": round(avg, 4), "ms_median": round(ms[len(ms) // 2], 4), "frac": round(pair / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
            "Mpix_s": round(nxo * nyo * nc / (avg * 1e-3) / 1e6, 1), "steps": steps,
            "first_call_s": round(first_s, 3), "held_after_call_GiB": round(held / 2**30, 2), "pair_GiB": round(pair / 2**30, 2),
-           "held_over_pair": round(held / pair, 3), "check": chk}
+           "held_over_pair": round(held / pair, 3), "allocation": alloc_info, "check": chk}
     plan.close()
     del out, m, src, dst3
     torch.cuda.empty_cache()
@@ -1053,7 +1073,58 @@ def gpu_evaluators(dev):
         "tan_proj.jl:44-57, two N-vectors, 1e8 points")
     rec("Gnomonic posmap 8192^2", _median_ms(lambda: pj.posmap((N, N), tan, device=dev), dev, reps=5), 16.0 * N * N, N * N, "Mpix_s",
         "enmap_ops.jl:190-203 on a Gnomonic WCS, write-only 16 B/pixel")
+    del ip, jp, tra, tdec
+    torch.cuda.empty_cache()
+    try:
+        out["CAR->TAN mosaic"] = tan_mosaic_record(dev)
+    except Exception as e:                                  # noqa: BLE001 -- a side measurement: reported, not fatal
+        out["CAR->TAN mosaic"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    torch.cuda.empty_cache()
     return out
+
+
+def tan_mosaic_record(dev, npatch=4096):
+    """SURVEY 8(f) N2 at scale: the full-sky 0.5-arcmin CAR map (7.5 GB) reprojected onto a mosaic of sixteen
+    Gnomonic patches of 4096^2 pixels of 0.5 arcmin (2.1 GB of output, far beyond the Infinity Cache), one pj.reproject call per
+    patch.  Algorithmic bytes = 8 B written + 8 B read per output pixel (the patches have the source's resolution).  A 128 x 64
+    window of the last patch is checked against the oracle's per-pixel evaluation (reference evaluators + libm) of the SAME
+    window geometry: the tiled kernel interpolates the coordinates within 1e-10 pixel, i.e. ~2e-10 in value on a white-noise map."""
+    import numpy as np
+    from oracle import oracle as O
+    shape, wcs = pj.fullsky_geometry(2 * math.pi / 43200)
+    m = pj.Enmap(torch.empty((shape[1], shape[0]), dtype=torch.float64, device=dev), wcs)
+    pj.fill_random_(m.data, 1234)
+    res = 0.5 / 60
+    patches = [pj.Gnomonic((res, res), (npatch / 2 + 0.5, npatch / 2 + 0.5), (float(ra), dec)) for dec in (-25.0, 25.0) for ra in range(0, 360, 45)]
+    outs = [None]
+
+    def run():
+        outs[0] = [pj.reproject(m, (npatch, npatch), w) for w in patches]
+    ms = _median_ms(run, dev, reps=3)
+    npix = len(patches) * npatch * npatch
+    alg = 16.0 * npix
+    # the check: a window of the last patch, as its own (shifted-crpix) Gnomonic geometry, through the oracle
+    w = patches[-1]
+    c0, r0, cw, rw = 1000, 3000, 128, 64
+    wwin = pj.Gnomonic(w.cdelt, (w.crpix[0] - c0, w.crpix[1] - r0), w.crval)
+    src_host = m.data.cpu().numpy()[None]
+    exp = O.reproject_generic(wcs, 0, (shape[0], shape[1], 1), src_host, wwin, 1, (cw, rw))[0]
+    got = outs[0][-1].data[r0:r0 + rw, c0:c0 + cw].cpu().numpy()
+    err = float(np.abs(got - exp).max())
+    ex, tot = 0, 0
+    try:
+        import ctypes as C
+        e_, t_ = C.c_int64(), C.c_int64()
+        pj._lib.check(pj.load_library().pxl_reproject_generic_last_tiles(C.byref(e_), C.byref(t_), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        ex, tot = e_.value, t_.value
+    except Exception:                                       # noqa: BLE001
+        pass
+    return {"ms": round(ms, 4), "GBs": round(alg / ms / 1e6, 1), "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "Gpix_s": round(npix / ms / 1e6, 1),
+            "patches": len(patches), "patch": [npatch, npatch], "algorithmic_bytes": alg,
+            "kernels": "k_generic_lattice + k_reproject_generic_tiled3 + k_reproject_generic_exact_tiles per patch",
+            "last_patch_exact_tiles": [ex, tot],
+            "check": {"max_abs_err_vs_oracle": err, "window": [cw, rw], "within_2e-9": bool(err < 2e-9)},
+            "reference": "pix2sky(out; tan_proj.jl:59-75) -> sky2pix(in; car_proj.jl:225-231, safe=true) -> 2x2 gather, coordinates interpolated per 128x32 tile with a 1e-10-pixel check"}
 
 
 def cpu_baseline_evaluators():

@@ -1177,7 +1177,7 @@ int pxl_reproject_generic_bilinear_f64(const pxl_car_wcs* wcs_in, int proj_in, c
         hipLaunchKernelGGL(k_reproject_generic_tiled, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, (const double2*)lat, (const int32_t*)flag);
     else
         hipLaunchKernelGGL(k_reproject_generic_tiled2, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, (const double2*)lat, (const int32_t*)flag);
-    hipLaunchKernelGGL(k_reproject_generic_exact_tiles, dim3((unsigned)std::min<int64_t>(ntiles, 1024)), dim3(256), 0, st, p, (const int32_t*)flag, gx, ntiles);
+    hipLaunchKernelGGL(k_reproject_generic_exact_tiles, dim3((unsigned)std::min<int64_t>(ntiles, 256)), dim3(256), 0, st, p, (const int32_t*)flag, gx, ntiles);
     int rc = check_launch("k_reproject_generic_tiled");
     hipError_t fe = hipFreeAsync(ws, st);
     if (fe != hipSuccess && rc == PXL_OK) rc = fail(PXL_EHIP, "reproject_generic: hipFreeAsync: %s", hipGetErrorString(fe));

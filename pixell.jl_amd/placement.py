@@ -380,6 +380,7 @@ def place_pair_native(src_shape, dst_shape, dtype=torch.float64, device="cuda", 
 import os as _os
 
 _POLICY = _os.environ.get("PXL_ALLOC_POLICY", "class-aware")
+_LAST_INFO = {}       # what the most recent empty_map() call did (diagnostics: pj.last_allocation_info())
 _LABELS = {}          # (device index, data_ptr, nbytes) -> (labels, num_device_free when they were measured)
 MIN_PLACED_BYTES = 3 * GiB
 
@@ -395,6 +396,11 @@ def set_allocation_policy(policy: str):
 
 def allocation_policy() -> str:
     return _POLICY
+
+
+def last_allocation_info() -> dict:
+    """The report of the most recent empty_map() call in this process (policy, tries, class shares, seconds, ballast)."""
+    return dict(_LAST_INFO)
 
 
 def _device_frees(dev):
@@ -435,7 +441,9 @@ def empty_map(shape, dtype=torch.float64, device="cuda", policy=None, budget_gib
     n = math.prod(shape)
     nbytes = n * esz
     if policy == "plain" or nbytes < MIN_PLACED_BYTES:
-        return torch.empty(tuple(shape), dtype=dtype, device=dev), {"policy": "plain" if policy == "plain" else "class-aware: below %d GiB, plain allocation" % (MIN_PLACED_BYTES // GiB), "tries": 1}
+        info = {"policy": "plain" if policy == "plain" else "class-aware: below %d GiB, plain allocation" % (MIN_PLACED_BYTES // GiB), "tries": 1}
+        _LAST_INFO.clear(); _LAST_INFO.update(info)
+        return torch.empty(tuple(shape), dtype=dtype, device=dev), info
     t0 = time.perf_counter()
     if budget_gib is None:
         budget_gib = float(_os.environ.get("PXL_ALLOC_BUDGET_GIB", "96"))
@@ -472,4 +480,5 @@ def empty_map(shape, dtype=torch.float64, device="cuda", policy=None, budget_gib
     how = ("two classes (%.0f %% of its windows in the second)" % (100 * share)) if share >= min_share else "one class (no boundary within the budget)"
     info = {"policy": "class-aware", "placement": how, "tries": len(shares), "candidates_minor_share": shares, "probes": probes,
             "seconds": round(time.perf_counter() - t0, 3), "transient_ballast_GiB": round(peak / GiB, 1), "held_GiB": round(nbytes / GiB, 2)}
+    _LAST_INFO.clear(); _LAST_INFO.update(info)
     return chosen.view(tuple(shape)), info

@@ -1,0 +1,35 @@
+#!/bin/bash
+# Round-4 evidence (run through gpurun from the repo root): tools/collect_r04.sh [tag]
+# Everything lands under gpurun_out/<tag>/; the summaries judged are copied into profiles/r04_* afterwards.
+set -o pipefail
+tag=${1:-r04_collect}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$R/gpurun_out/$tag
+mkdir -p $out
+cd $R
+timeout -k 10 900 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; echo rc=$? >> $out/pytest_gpu.log; tail -3 $out/pytest_gpu.log | cut -c1-200
+echo "== default bench"; timeout -k 10 900 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err; echo rc=$?
+cd /tmp && export TMPDIR=/tmp
+for wl in cfg4 cfg3 cfg3s; do
+  echo "== $wl: kernel stats + traffic"
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$wl -- python3 $R/bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline --no-configs --no-traffic --sustain-seconds 0 > $out/bench_${wl}_under_stats.json 2> /dev/null
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch_$wl -- python3 $R/bench.py --workload $wl --steps 5 --warmup 1 --no-cpu-baseline --no-configs --no-traffic --sustain-seconds 0 > /dev/null 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write_$wl -- python3 $R/bench.py --workload $wl --steps 5 --warmup 1 --no-cpu-baseline --no-configs --no-traffic --sustain-seconds 0 > /dev/null 2>&1
+done
+echo "== cfg5: kernel stats + counters (1e9 points)"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_cfg5 -- python3 $R/bench.py --workload cfg5 --steps 5 --warmup 1 > $out/bench_cfg5_under_stats.json 2> /dev/null
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" \
+           "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD" "GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  PXL_BENCH_POINTS=2e8 PXL_BENCH_SAMPLER=pairs timeout -k 10 240 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/pmc$i -- python3 $R/bench.py --workload cfg5 --steps 3 --warmup 1 > /dev/null 2> $out/pmc$i.err || { echo "cfg5 pass $i failed"; tail -2 $out/pmc$i.err; }
+done
+python3 $R/tools/summarize_pmc.py $out k_sample k_build_rowpairs > $out/cfg5_counters.txt; tail -40 $out/cfg5_counters.txt
+echo "== CAR->TAN mosaic: kernel stats"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_mosaic -- python3 $R/tools/bench_tan_mosaic.py > $out/mosaic_under_stats.txt 2> /dev/null
+cat $out/stats_mosaic/*/*kernel_stats.csv | grep "generic\|lattice" | cut -c1-160
+timeout -k 10 300 python3 $R/tools/bench_tan_mosaic.py 2>&1 | grep -v amdgpu.ids > $out/mosaic.txt; cut -c1-300 $out/mosaic.txt
+echo "== unwind kernel stats"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_unwind -- python3 $R/tools/prof_unwind.py > $out/unwind_under_stats.txt 2>&1
+cat $out/stats_unwind/*/*kernel_stats.csv | grep -i "unwind\|scan" | cut -c1-170
+echo "== tan evaluators"; timeout -k 10 200 python3 $R/tools/bench_tan_evaluators.py 2>&1 | grep -v amdgpu.ids | tee $out/tan_evaluators.jsonl
