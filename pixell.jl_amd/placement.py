@@ -374,7 +374,8 @@ def place_pair_native(src_shape, dst_shape, dtype=torch.float64, device="cuda", 
 # allocate through.  "class-aware" (the default): a destination of 3 GiB or more is allocated on its own and its 1 GiB windows
 # are labelled with the store probe; a candidate that lies inside ONE memory class is kept as ballast while the next one is
 # tried (consecutive allocations walk through the device's memory: a class boundary is at most one class run away, 4-32 GiB on
-# the boxes seen), and all ballast goes back to the driver before the call returns -- afterwards exactly the map is allocated,
+# the boxes seen; a candidate with 30 % of its windows in a second class is taken at once -- with six windows in a 7 GiB map the
+# shares come in sixths, and holding out for 40 % cost 14 tries and 6 s where the first try already had 33 %), and all ballast goes back to the driver before the call returns -- afterwards exactly the map is allocated,
 # no head-room.  "plain": torch.empty, nothing probed.  PXL_ALLOC_POLICY / set_allocation_policy() choose; PXL_ALLOC_BUDGET_GIB
 # bounds the transient ballast (default 96, and never more than the free memory less 8 GiB).
 import os as _os
@@ -427,7 +428,7 @@ def _labels_of(t: torch.Tensor):
     return labels, cinfo.get("probes", 0)
 
 
-def empty_map(shape, dtype=torch.float64, device="cuda", policy=None, budget_gib=None, accept_share=0.4, min_share=0.2, max_tries=24):
+def empty_map(shape, dtype=torch.float64, device="cuda", policy=None, budget_gib=None, accept_share=0.3, min_share=0.2, max_tries=24):
     """(tensor, info): an uninitialised device tensor of `shape` allocated by the library's policy (above).  Contents are
     unspecified (probed windows hold zeros).  info says what was done: policy, tries, the share of the buffer's windows in its
     second class, seconds spent, bytes of ballast held transiently."""

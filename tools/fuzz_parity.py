@@ -26,7 +26,7 @@ import pixell_jl_amd as pj       # noqa: E402
 from oracle import oracle as O   # noqa: E402
 
 DEV = None
-KNOBS = ("PXL_REPROJECT_RH", "PXL_REPROJECT_PAIRS", "PXL_REPROJECT_NS", "PXL_REPROJECT_PF")
+KNOBS = ("PXL_REPROJECT_RH", "PXL_REPROJECT_PAIRS", "PXL_REPROJECT_NS", "PXL_REPROJECT_PF", "PXL_REPROJECT_NT")
 PAD = 4099      # canary elements either side of an output buffer
 
 
@@ -145,6 +145,8 @@ def fuzz_reproject(rng):
         knobs["PXL_REPROJECT_RH"] = str(rng.choice([1, 2, 3, 8, 16, 32, 64]))
     if rng.random() < 0.6:
         knobs["PXL_REPROJECT_PAIRS"] = str(rng.choice([1, 2, 4]))
+    if rng.random() < 0.4:
+        knobs["PXL_REPROJECT_NT"] = str(rng.choice([0, 1]))           # non-temporal (the default since round 4) / plain stores
     if rng.random() < 0.4:
         knobs["PXL_REPROJECT_NS"] = str(rng.choice([2, 3, 4, 8]))
     if rng.random() < 0.4:
@@ -276,6 +278,15 @@ def fuzz_unwind(rng):
         got = pj.unwind_(to_dev(two), period, ref).cpu().numpy()
         exp = np.stack([O.unwind_row(two[:, 0].copy(), period, ref), O.unwind_row(two[:, 1].copy(), period, ref)], axis=1)
         assert bits_equal(got, exp), ("2xN", params)
+        # pix2sky!(safe=true) OUT OF PLACE through an identity WCS: the one-pass kernel (decoupled look-back) beyond 8192 points,
+        # the single-block form below; in place: the two-pass form.  Period 2 pi, ref 0 are the evaluator's own.
+        ident = ((10, 10), pj.CarClenshawCurtis((1.0, 1.0), (0.0, 0.0), (0.0, 0.0), 1.0))
+        d = to_dev(two)
+        exp = O.pix2sky(ident[1], two, O.WRAP_UNWIND)
+        got = pj.pix2sky_(ident, d, torch.empty_like(d), safe=True).cpu().numpy()
+        assert bits_equal(got, exp), ("pix2sky! out of place", params)
+        got = pj.pix2sky_(ident, d, d, safe=True).cpu().numpy()
+        assert bits_equal(got, exp), ("pix2sky! in place", params)
     return kind
 
 
