@@ -449,6 +449,9 @@ __device__ inline unsigned long long uw_peek(const unsigned long long* p) {
 #ifndef PXL_UW1_WAVES
 #define PXL_UW1_WAVES 16
 #endif
+#ifndef PXL_UW1_WIN
+#define PXL_UW1_WIN 4          // 64-link windows wave 0 reads per look-back round
+#endif
 template <class SRC>
 __global__ __launch_bounds__(64 * PXL_UW1_WAVES) void k_unwind_onepass(SRC src, typename SRC::raw_t* out, int64_t n, UwLink* __restrict__ links,
                                                                        unsigned int* __restrict__ ticket, int32_t* __restrict__ flag) {
@@ -509,42 +512,59 @@ __global__ __launch_bounds__(64 * PXL_UW1_WAVES) void k_unwind_onepass(SRC src, 
         unsigned int nan_before = 0;
         bool gave_up = false;
         if (id > 0) {
+            // PXL_UW1_WIN windows of 64 links per round, their loads issued together: a workgroup that starts with all its ~500
+            // resident predecessors still computing has to walk back through all of them, and a window at a time that was eight
+            // dependent round trips with 15 waves idle at the barrier
             int64_t top = id - 1;
             unsigned int polls = 0;
             for (;;) {
-                const int64_t j = top - lane;
-                unsigned long long a = 0, p0 = 0, p1 = 0;
-                if (j >= 0) {
-                    p0 = uw_peek(&links[j].pre0);
-                    p1 = NROW == 2 ? uw_peek(&links[j].pre1) : p0;
-                    a = uw_peek(&links[j].agg);
+                unsigned long long a[PXL_UW1_WIN], p0[PXL_UW1_WIN], p1[PXL_UW1_WIN];
+#pragma unroll
+                for (int wdw = 0; wdw < PXL_UW1_WIN; ++wdw) {
+                    const int64_t j = top - 64 * wdw - lane;
+                    a[wdw] = 0; p0[wdw] = 0; p1[wdw] = 0;
+                    if (j >= 0) {
+                        p0[wdw] = uw_peek(&links[j].pre0);
+                        p1[wdw] = NROW == 2 ? uw_peek(&links[j].pre1) : p0[wdw];
+                        a[wdw] = uw_peek(&links[j].agg);
+                    }
                 }
-                // chunks before the first one: an inclusive prefix of zero
-                const bool hasP = j < 0 || (((unsigned)p0 & 1u) && ((unsigned)p1 & 1u));
-                const bool hasA = j < 0 || ((unsigned)a & 1u);
-                const unsigned long long pmask = __ballot(hasP), amask = __ballot(hasA);
-                const int first = pmask ? __builtin_ctzll(pmask) : 64;          // nearest link with a prefix
-                const unsigned long long need = first >= 64 ? ~0ull : ((1ull << first) - 1ull);
-                if ((amask & need) != need) {                                    // an aggregate in between is not there yet
+                int e0 = 0, e1 = 0;
+                unsigned int en = 0;
+                int state = 0;                   // 0: no prefix met yet; 1: done; 2: an aggregate is missing before the first prefix
+#pragma unroll
+                for (int wdw = 0; wdw < PXL_UW1_WIN; ++wdw) {
+                    const int64_t j = top - 64 * wdw - lane;
+                    // chunks before the first one: an inclusive prefix of zero
+                    const bool hasP = j < 0 || (((unsigned)p0[wdw] & 1u) && ((unsigned)p1[wdw] & 1u));
+                    const bool hasA = j < 0 || ((unsigned)a[wdw] & 1u);
+                    const unsigned long long pmask = __ballot(hasP), amask = __ballot(hasA);
+                    const int first = pmask ? __builtin_ctzll(pmask) : 64;          // nearest link of this window with a prefix
+                    const unsigned long long need = first >= 64 ? ~0ull : ((1ull << first) - 1ull);
+                    int c0 = 0, c1 = 0;
+                    unsigned int nb = 0;
+                    if (j >= 0 && lane < first) {
+                        const unsigned int pa = (unsigned)(a[wdw] >> 32);
+                        c0 = (int)(pa & 0x3fffu) - 8192; c1 = (int)((pa >> 14) & 0x3fffu) - 8192; nb = pa >> 28;
+                    } else if (j >= 0 && lane == first) {
+                        c0 = (int)(unsigned)(p0[wdw] >> 32); c1 = (int)(unsigned)(p1[wdw] >> 32);
+                        nb = (((unsigned)p0[wdw] >> 1) & 1u) | ((((unsigned)p1[wdw] >> 1) & 1u) << 1);
+                    }
+                    const int s0 = uw_wave_total(c0), s1 = NROW == 2 ? uw_wave_total(c1) : 0;
+                    const unsigned int nbw = (__ballot(nb & 1u) != 0ull ? 1u : 0u) | (__ballot(nb & 2u) != 0ull ? 2u : 0u);
+                    if (state == 0) {
+                        if ((amask & need) != need) state = 2;
+                        else { e0 += s0; e1 += s1; en |= nbw; if (first < 64) state = 1; }
+                    }
+                }
+                if (state == 2) {                                                // an aggregate in between is not there yet
                     if (++polls > (1u << 22)) { gave_up = true; break; }
                     __builtin_amdgcn_s_sleep(2);
                     continue;
                 }
-                int c0 = 0, c1 = 0;
-                unsigned int nb = 0;
-                if (j >= 0 && lane < first) {
-                    const unsigned int pa = (unsigned)(a >> 32);
-                    c0 = (int)(pa & 0x3fffu) - 8192; c1 = (int)((pa >> 14) & 0x3fffu) - 8192; nb = pa >> 28;
-                } else if (j >= 0 && lane == first) {
-                    c0 = (int)(unsigned)(p0 >> 32); c1 = (int)(unsigned)(p1 >> 32);
-                    nb = (((unsigned)p0 >> 1) & 1u) | ((((unsigned)p1 >> 1) & 1u) << 1);
-                }
-                E[0] += uw_wave_total(c0);
-                if (NROW == 2) E[1] += uw_wave_total(c1);
-                if (__ballot(nb & 1u) != 0ull) nan_before |= 1u;
-                if (__ballot(nb & 2u) != 0ull) nan_before |= 2u;
-                if (first < 64) break;
-                top -= 64;
+                E[0] += e0; E[1] += e1; nan_before |= en;
+                if (state == 1) break;
+                top -= 64 * PXL_UW1_WIN;
                 polls = 0;
             }
         }
