@@ -385,6 +385,9 @@ __global__ __launch_bounds__(256) void k_reproject_generic_tiled2(GenericParams 
 //   * rows that fail the test anywhere in the wave (seam, edges, horizon, NaN) are redone afterwards by generic_store, one
 //     non-unrolled copy of the general code.
 // Same operations on the same operands as generic_store's interior path: the bits are those of round 3's kernel.
+// Measured and dropped on top of this form (round 4, 16-patch mosaic, one box): 16-byte stores from one-pixel lanes by a DPP swap
+// between lanes 2k and 2k+1 (half the store instructions: 1.438 against 1.357 ms -- slower); the exact fallback folded into the
+// lattice launch so that the third launch disappears (1.357 against 1.355 ms: nothing, and 112 VGPRs in the lattice kernel).
 __global__ __launch_bounds__(256) void k_reproject_generic_tiled3(GenericParams p, const double2* __restrict__ lat,
                                                                   const int32_t* __restrict__ flag) {
     const int64_t tile = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;

@@ -450,8 +450,9 @@ __device__ inline unsigned long long uw_peek(const unsigned long long* p) {
 #define PXL_UW1_WAVES 16
 #endif
 #ifndef PXL_UW1_WIN
-#define PXL_UW1_WIN 4          // 64-link windows wave 0 reads per look-back round
-#endif
+#define PXL_UW1_WIN 1          // 64-link windows wave 0 reads per look-back round.  2 / 4 / 8 windows with their loads issued together cut
+#endif                         // the round trips but cost 12 VGPRs each (62 -> 74 / 84 / 126: the second 16-wave workgroup no longer fits a CU):
+                               // 0.89 / 0.98-1.01 / 1.03 / 1.23 ms per 1e8 points (round 4, one box)
 template <class SRC>
 __global__ __launch_bounds__(64 * PXL_UW1_WAVES) void k_unwind_onepass(SRC src, typename SRC::raw_t* out, int64_t n, UwLink* __restrict__ links,
                                                                        unsigned int* __restrict__ ticket, int32_t* __restrict__ flag) {
@@ -512,9 +513,7 @@ __global__ __launch_bounds__(64 * PXL_UW1_WAVES) void k_unwind_onepass(SRC src, 
         unsigned int nan_before = 0;
         bool gave_up = false;
         if (id > 0) {
-            // PXL_UW1_WIN windows of 64 links per round, their loads issued together: a workgroup that starts with all its ~500
-            // resident predecessors still computing has to walk back through all of them, and a window at a time that was eight
-            // dependent round trips with 15 waves idle at the barrier
+            // PXL_UW1_WIN windows of 64 links per round (1: more windows per round were measured slower, see the define)
             int64_t top = id - 1;
             unsigned int polls = 0;
             for (;;) {
