@@ -370,7 +370,7 @@ def main():
                          "memory classes mapped with the library's store probe (pxl_mem_probe_pair, ~100 probes of 0.3 ms), the destination "
                          "put across a class boundary, the source in a class it does not touch.  The reprojection's eight XCD write fronts "
                          "store at 6.8-7.1 TB/s split over two classes and at 5.8-6.0 TB/s inside one, which is where a plain allocation "
-                         "normally lies (DESIGN 9 item 6).  Topology discovery by a fixed rule: nothing about this workload is timed, no "
+                         "normally lies (DESIGN 4.7; history: docs/DESIGN_history_r01-r03.md 9 item 6).  Topology discovery by a fixed rule: nothing about this workload is timed, no "
                          "candidates are compared.  With N > 1 every rank places its own strip pair.  The default run also reports the "
                          "plain first placement of the same workload (configs.*.plain_first_placement)")
     ap.add_argument("--arena", dest="arena", action="store_true",
@@ -1037,7 +1037,7 @@ def gpu_evaluators(dev):
     rec("posmap", _median_ms(posmap, dev), 16.0 * npx, npx, "Mpix_s", "enmap_ops.jl:190-203 (safe=true), 43200x21601, write-only 16 B/pixel; two plain allocations")
     del ra, dec
     torch.cuda.empty_cache()
-    try:    # the same launch with its two output maps in different memory classes (pj.place_streams; DESIGN 9 item 6)
+    try:    # the same launch with its two output maps in different memory classes (pj.place_streams; DESIGN 4.7)
         (ra, dec), sinfo = pj.place_streams([(shape[1], shape[0])] * 2, device=dev)
         rec("posmap, RA and DEC maps in different memory classes", _median_ms(posmap, dev), 16.0 * npx, npx, "Mpix_s",
             "the same launch; buffers from pj.place_streams: classes %s" % [b["class"] for b in sinfo["buffers"]])

@@ -262,7 +262,7 @@ int pxl_fits_encode_f64(const double* src, void* raw_be, int64_t n, void* stream
 int pxl_fits_swap_f32(const void* src, void* dst, int64_t n, void* stream);
 
 /* ---- Placement probe.  The memory of a hipMalloc'ed allocation on the MI355X falls into three classes (thirds of the 288 GiB:
- *      DESIGN.md 9, profiles/r03_xcd_classes.txt): a kernel with several far-apart WRITE fronts -- the reprojection keeps one
+ *      DESIGN.md 4.7, profiles/r03_xcd_classes.txt): a kernel with several far-apart WRITE fronts -- the reprojection keeps one
  *      per XCD -- stores at 5.8-6.0 TB/s when all of them lie in one class and at 6.8-7.1 TB/s when they are split over two.
  *      This entry times the pattern that defines the classes: eight store fronts (one per XCD), four in window a and four in
  *      window b, each writing window_bytes / 4 bytes of ZEROS (both windows are overwritten).  `us` receives the median of

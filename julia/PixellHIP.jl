@@ -439,7 +439,7 @@ sharded_step!(dst, plan, src, own_rows, sends, recvs, comm::PxlComm) = sharded_s
 comm_destroy(c::PxlComm) = check(ccall((:pxl_comm_destroy, libpixell_hip), Cint, (Ptr{Cvoid},), c.handle))
 comm_backend() = unsafe_string(ccall((:pxl_comm_backend, libpixell_hip), Cstring, ()))
 
-# ---- class-aware placement of a (source, destination) pair (DESIGN.md section 9 item 6; pixell.jl_amd/placement.py is the Python twin).
+# ---- class-aware placement of a (source, destination) pair (DESIGN.md section 4.7; pixell.jl_amd/placement.py is the Python twin).
 # The memory of an allocation falls into three classes; a kernel with several far-apart write fronts (the reprojection: one per
 # XCD) stores at 5.8-6.0 TB/s into one class and at 6.8-7.1 TB/s when its destination straddles two.  `mem_probe_pair` times the
 # 8-front store probe on two windows (it overwrites them with zeros): slow = same class.

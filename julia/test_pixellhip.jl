@@ -142,8 +142,27 @@ end
     @test lo + (lo == UInt(src.ptr) ? sizeof(Float64) * prod(size(src)) : sizeof(Float64) * prod(size(dst))) <= hi
     @test all(==(0.0), Array(src)[1:1000])                              # the source is zero-filled
     offs, labels = PixellHIP.map_classes(src.parent)
-    @test 1 <= maximum(labels) <= 3                                     # the three memory classes of the part (DESIGN.md section 9 item 6)
+    @test 1 <= maximum(labels) <= 3                                     # the three memory classes of the part (DESIGN.md section 4.7)
     plan = PixellHIP.ReprojectPlan(fullsky_geometry(deg2rad(1 / 60))..., fullsky_geometry(deg2rad(0.5 / 60))...)
     PixellHIP.reproject!(dst, plan, src)
     @test all(==(0.0), Array(dst)[1:1000])
+end
+
+@testset "the library's allocation policy behind HIPArray(undef, ...) / similar" begin
+    # enmap.jl:60-62: `similar` keeps the array type, so every fresh device map comes from HIPArray{T,N}(undef, dims), i.e. from
+    # pxl_mem_alloc_placed (include/pixell_hip.h): map-sized buffers across two memory classes, no head-room kept; small ones plain
+    @test PixellHIP.ALLOC_POLICY[] === :class_aware
+    big = HIPArray{Float64}(undef, 43200, 21601)                        # 7.5 GB: goes through the class search
+    @test size(big) == (43200, 21601) && UInt(big.ptr) % 256 == 0
+    small = similar(big, Float64, (128, 64))                            # below 3 GiB: a plain allocation through the same entry
+    @test size(small) == (128, 64)
+    m = Enmap(HIPArray(ones(360, 181)), fullsky_geometry(deg2rad(1))[2])
+    @test similar(m) isa Enmap && parent(similar(m)) isa HIPArray       # the reference's own `similar(::Enmap)` lands here
+    PixellHIP.ALLOC_POLICY[] = :plain
+    try
+        plain = HIPArray{Float64}(undef, 4096, 4096)
+        @test size(plain) == (4096, 4096)
+    finally
+        PixellHIP.ALLOC_POLICY[] = :class_aware
+    end
 end

@@ -54,7 +54,7 @@ struct ReprojParams {
 // an eighth of the map apart.  The grid must cover ceil(ntiles / (8 chunk)) * 8 chunk blocks.
 // order: 0 = every XCD walks its piece upwards from its start (eight write fronts a piece apart, moving in lockstep);
 // 1 = odd XCDs walk downwards (the distances between fronts change all the time); 2 = XCD v starts v/8 of the way into
-// its piece and wraps around (fronts 9/8 of a piece apart).  Experiments on the write-placement effect.
+// its piece and wraps around (fronts 9/8 of a piece apart).  Experiments on the write-placement effect (history: docs/DESIGN_history_r01-r03.md 9 item 6).
 __device__ inline int64_t xcd_tile(int64_t b, int64_t chunk, int order = 0) {
     const int64_t v = b & 7, j = b >> 3;
     const int64_t c = j / chunk;

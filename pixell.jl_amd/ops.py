@@ -378,7 +378,7 @@ def reproject(m: Enmap, shape_out, wcs_out, out: Enmap = None, plan: ReprojectPl
     if out is None:
         # the library's allocation policy for map-sized outputs (placement.empty_map): by default a destination of 3 GiB or more
         # is placed across a boundary between two memory classes of the HBM -- no head-room is kept -- because the kernel's
-        # eight write fronts store 15 % faster there (DESIGN 6 / 9); PXL_ALLOC_POLICY=plain or pj.set_allocation_policy("plain")
+        # eight write fronts store 15 % faster there (DESIGN 4.7); PXL_ALLOC_POLICY=plain or pj.set_allocation_policy("plain")
         # turn that into torch.empty.  Allocate once and pass `out=` (and `plan=`) when reprojecting repeatedly.
         oshape = (nyo, nxo) if m.data.dim() == 2 else (m.data.shape[0], nyo, nxo)
         data, _info = placement.empty_map(oshape, dtype=m.data.dtype, device=m.device)

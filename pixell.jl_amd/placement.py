@@ -1,6 +1,6 @@
 """Class-aware placement of a (source, destination) pair of maps in MI355X HBM.
 
-Round 3 found why the same reprojection ran 10-17 % faster with its destination "in some places" (DESIGN.md 9, item 6;
+Round 3 found why the same reprojection ran 10-17 % faster with its destination "in some places" (docs/DESIGN_history_r01-r03.md 9 item 6;
 profiles/r03_xcd_classes.txt, r03_scan_placement_*.jsonl): the memory of a hipMalloc'ed allocation falls into three classes
 (thirds of the 288 GiB), and a kernel with several far-apart WRITE fronts -- the reprojection keeps one per XCD -- stores at
 5.8-6.0 TB/s when all fronts lie in one class and at 6.8-7.1 TB/s when they are split over two.  A plain allocation is made of

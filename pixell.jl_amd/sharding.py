@@ -211,7 +211,7 @@ class DecStripReprojector(DecStripLayout):
         ms for 22 GB, same kernel; tools/research/exp_placement_vmm.cpp, profiles/r02_placement_arena.jsonl).  For the
         0.5-arcmin IQU map this arrangement measured 7.2-7.37 ms in 20 of 24 processes on 9 boxes (two allocations: 7.2-8.1,
         about half of them slow, on some boxes every time); for the 2x-refinement workloads it is within 1 % of two
-        allocations either way (profiles/r02_ab_arena_*.txt, DESIGN 9 item 6).  bench.py allocates through it.
+        allocations either way (profiles/r02_ab_arena_*.txt, DESIGN 4.7).  bench.py allocates through it.
         Returns (src zero-filled, dst, arena) -- keep `arena` alive."""
         ns = 1
         for d in self.src_tensor_shape():

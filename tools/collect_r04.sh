@@ -29,6 +29,12 @@ echo "== CAR->TAN mosaic: kernel stats"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_mosaic -- python3 $R/tools/bench_tan_mosaic.py > $out/mosaic_under_stats.txt 2> /dev/null
 cat $out/stats_mosaic/*/*kernel_stats.csv | grep "generic\|lattice" | cut -c1-160
 timeout -k 10 300 python3 $R/tools/bench_tan_mosaic.py 2>&1 | grep -v amdgpu.ids > $out/mosaic.txt; cut -c1-300 $out/mosaic.txt
+j=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_WAVES" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum" "GRBM_GUI_ACTIVE"; do
+  j=$((j+1))
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/mosaic_pmc/pmc$j -- python3 $R/tools/bench_tan_mosaic.py > /dev/null 2> $out/mosaic_pmc$j.err || { echo "mosaic pass $j failed"; tail -2 $out/mosaic_pmc$j.err; }
+done
+python3 $R/tools/summarize_pmc.py $out/mosaic_pmc k_reproject_generic_tiled3 k_generic_lattice > $out/mosaic_counters.txt; cat $out/mosaic_counters.txt
 echo "== unwind kernel stats"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_unwind -- python3 $R/tools/prof_unwind.py > $out/unwind_under_stats.txt 2>&1
 cat $out/stats_unwind/*/*kernel_stats.csv | grep -i "unwind\|scan" | cut -c1-170
