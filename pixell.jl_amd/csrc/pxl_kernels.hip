@@ -1170,13 +1170,12 @@ int pxl_reproject_generic_bilinear_f64(const pxl_car_wcs* wcs_in, int proj_in, c
     double2* lat = (double2*)ws;
     int32_t* flag = (int32_t*)(ws + lat_bytes);
     hipLaunchKernelGGL(k_generic_lattice, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, p, gx, ntiles, lat, flag);
-    const int gv = env_int("PXL_GENERIC_V", 3);
-    if (gv == 3)
-        hipLaunchKernelGGL(k_reproject_generic_tiled3, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, (const double2*)lat, (const int32_t*)flag);
-    else if (gv == 1 || env_int("PXL_GENERIC_V1", 0))       // round 3's pixel kernel (one pixel per lane, 8-byte taps and stores): kept for A/B
+    // PXL_GENERIC_V=1: round 3's pixel kernel (one pixel per lane, 8-byte taps, ~99 VALU per pixel), kept for A/B; default: the lean
+    // round-4 form.  (Two more forms were built, measured slower and moved to tools/research/: two pixels per lane, the LDS ring.)
+    if (env_int("PXL_GENERIC_V", 3) == 1 || env_int("PXL_GENERIC_V1", 0))
         hipLaunchKernelGGL(k_reproject_generic_tiled, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, (const double2*)lat, (const int32_t*)flag);
     else
-        hipLaunchKernelGGL(k_reproject_generic_tiled2, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, (const double2*)lat, (const int32_t*)flag);
+        hipLaunchKernelGGL(k_reproject_generic_tiled3, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, (const double2*)lat, (const int32_t*)flag);
     hipLaunchKernelGGL(k_reproject_generic_exact_tiles, dim3((unsigned)std::min<int64_t>(ntiles, 256)), dim3(256), 0, st, p, (const int32_t*)flag, gx, ntiles);
     int rc = check_launch("k_reproject_generic_tiled");
     hipError_t fe = hipFreeAsync(ws, st);
