@@ -925,6 +925,13 @@ def side_measurements(args, dev, result):
             cfgs["cfg5"]["traffic_note"] = "live measurement failed: %s" % (det,)
     torch.cuda.empty_cache()
     result["configs"] = cfgs
+    # the headline's workload under the two other allocation policies, at the top of the roofline block
+    if "cfg4" in cfgs and "roofline" in result:
+        result["roofline"]["headline_allocation_policy"] = {True: "plain (alloc_pair)", False: "two plain allocations", "placed": "pj.place_pair (144 GiB head-room)",
+                                                            "api": "the library's default (pj.empty_map: class-aware, no head-room)"}.get(args.arena, str(args.arena))
+        result["roofline"]["frac_other_policies"] = {"class_aware_placement_144GiB_headroom": cfgs["cfg4"]["class_aware_placement"]["frac"],
+                                                     "plain_first_placement": cfgs["cfg4"]["plain_first_placement"]["frac"],
+                                                     "api_default_through_pj_reproject": cfgs["cfg4"]["api_default"]["frac"]}
     result["evaluators"] = gpu_evaluators(dev)
     torch.cuda.empty_cache()
     if "cpu_baseline" in result:

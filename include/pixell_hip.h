@@ -303,7 +303,7 @@ int pxl_mem_pair_free(pxl_mem_pair* pair);
  * bytes that lies in TWO memory classes, with NO head-room kept: the buffer is allocated on its own (hipMalloc), its 1 GiB
  * windows are labelled with the probe above, and while it lies inside one class it is held as ballast and the next allocation
  * is tried (consecutive allocations walk through the device's memory; a class run is 4-32 GiB long).  A candidate with at least
- * 30 % of its windows in a second class is taken at once; otherwise the best one seen within `budget_bytes` of ballast (0 = 96
+ * 30 % of its windows in a second class (20 % for buffers of 16 GiB and more) is taken at once; otherwise the best one seen within `budget_bytes` of ballast (0 = 96
  * GiB; never more than the free memory less 8 GiB) and 24 tries.  All ballast is freed before the call returns.  Buffers
  * below 3 GiB are plain allocations.  The same fixed rule as pixell.jl_amd/placement.py::empty_map (what pj.reproject allocates
  * its output with); topology discovery only, nothing about the caller's kernel is timed.  Contents unspecified (probed windows

@@ -213,7 +213,8 @@ int pxl_mem_alloc_placed(uint64_t bytes, uint64_t budget_bytes, void** out, pxl_
         peak = std::max(peak, held);
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
-        if (best_share >= 30 || tries >= 24 || held + bytes > budget_bytes || free_b < bytes + 8 * GiB) break;
+        // (16 GiB and more: the driver builds such a buffer from several blocks and every candidate shows ~20 % in a second class)
+        if (best_share >= 30 || (bytes >= 16 * GiB && best_share >= 20) || tries >= 24 || held + bytes > budget_bytes || free_b < bytes + 8 * GiB) break;
     }
     for (char* b : ballast) (void)hipFree(b);
     if (rc) { if (best) (void)hipFree(best); return rc; }

@@ -468,7 +468,10 @@ def empty_map(shape, dtype=torch.float64, device="cuda", policy=None, budget_gib
             cand = None
             held = sum(b.numel() * esz for b in ballast)
             free, _t = torch.cuda.mem_get_info(dev)
-            if best[0] >= accept_share or len(shares) >= max_tries or held + nbytes > budget_gib * GiB or free < nbytes + 8 * GiB:
+            # a map of 16 GiB or more is built by the driver from several blocks and shows ~20 % of its windows in a second class in
+            # EVERY candidate (five tries, 83 GiB of ballast and 3 s bought nothing on the 21 GiB IQU map): the first such one is taken
+            big_enough = nbytes >= 16 * GiB and best[0] >= min_share
+            if best[0] >= accept_share or big_enough or len(shares) >= max_tries or held + nbytes > budget_gib * GiB or free < nbytes + 8 * GiB:
                 break
         chosen = best[1]
         freed = bool(ballast)
