@@ -545,6 +545,50 @@ def test_unwind_one_pass_equals_two_pass(pj, O, dev):
         assert _same_bits_or_nan(two, exp), name
 
 
+def test_unwind_in_range_vote_bit_exact(pj, O, dev):
+    """The unwind sources skip the exact-fmod machinery when a whole wave's coordinates already lie in [ref - P/2, ref + P/2)
+    (a wave vote; `UwSrcPix2::to_m` / `UwSrcAng2::to_m`).  Same bits as the general path: batches where every wave votes yes,
+    batches where waves alternate, the interval's end points and their neighbours, a real full-sky geometry, long and short
+    batches (one-pass, two-pass and single-block kernels), and `unwind!` with a reference that is not zero."""
+    rng = np.random.default_rng(77)
+    ident = _identity_wcs(pj)
+    pi = math.pi
+    edge = np.array([-pi, np.nextafter(-pi, 0), np.nextafter(-pi, -4), pi, np.nextafter(pi, 0), np.nextafter(pi, 4), 0.0, -0.0, 1e-300, -1e-300])
+    for n in (700, 50_000, 1_200_003):
+        inside = rng.uniform(-pi, pi, (n, 2))
+        inside[:, 1] = rng.uniform(-pi / 2, pi / 2, n)
+        mixed = inside.copy()
+        blocks = (np.arange(n) // 64) % 3 == 1                       # every third wave leaves the interval
+        mixed[blocks, 0] += rng.choice([-4, -2, 2, 6], blocks.sum()) * pi
+        edges = inside.copy()
+        at = rng.integers(0, n, 4 * len(edge))
+        edges[at, 0] = np.tile(edge, 4)
+        edges[at[::2], 1] = np.tile(edge, 4)[::2]
+        for name, a in (("inside", inside), ("mixed", mixed), ("edges", edges)):
+            exp = O.pix2sky(ident[1], a, O.WRAP_UNWIND)
+            d = to_dev(a, dev)
+            assert bits_equal(pj.pix2sky_(ident, d, torch.empty_like(d), safe=True).cpu().numpy(), exp), (name, n, "out of place")
+            assert bits_equal(pj.pix2sky_(ident, d, d, safe=True).cpu().numpy(), exp), (name, n, "in place")
+    # a real geometry: every pixel of the map is inside the interval, half a pixel beyond the seam is not
+    shape, wcs = pj.fullsky_geometry(2 * pi / 21600)
+    n = 400_001
+    pix = np.stack([rng.uniform(0.5, shape[0] + 0.5, n), rng.uniform(1, shape[1], n)], axis=1)
+    pix[::4097, 0] = rng.choice([-3.0, 0.25, shape[0] + 0.75, 3.0 * shape[0]], len(pix[::4097]))
+    exp = O.pix2sky(wcs, pix, O.WRAP_UNWIND)
+    d = to_dev(pix, dev)
+    assert bits_equal(pj.pix2sky_((shape, wcs), d, torch.empty_like(d), safe=True).cpu().numpy(), exp)
+    # unwind! with its own period and reference
+    for period, ref in ((2 * pi, 0.0), (360.0, 180.0), (1.0, -0.3)):
+        for n in (900, 300_001):
+            a = ref + rng.uniform(-period / 2, period / 2, (n, 2))
+            a[at[at < n], 0] = ref + rng.choice([-period / 2, period / 2, np.nextafter(period / 2, 0)], (at < n).sum())
+            b = a.copy()
+            b[(np.arange(n) // 64) % 2 == 1, 1] += 3 * period
+            for name, x in (("inside", a), ("mixed", b)):
+                exp = np.stack([O.unwind_row(x[:, 0].copy(), period, ref), O.unwind_row(x[:, 1].copy(), period, ref)], axis=1)
+                assert bits_equal(pj.unwind_(to_dev(x, dev), period, ref).cpu().numpy(), exp), (name, n, period, ref)
+
+
 def test_unwind_ties_and_nonfinite(pj, O, dev):
     """Adversarial inputs: steps of exactly half a period (rint ties-to-even decides), and NaN/Inf, which in
     the sequential recurrence poison every later element -- the verified scan must hand those to the serial
