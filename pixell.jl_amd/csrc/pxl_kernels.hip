@@ -192,7 +192,7 @@ static int unwind_ws_alloc(int64_t n, int nrow, hipStream_t st, UnwindWs* w) {
     const size_t bytes_c = w->multipass ? up((size_t)nrow * n) : 0, bytes_r = w->multipass ? up((size_t)4 * nrow * n) : 0,
                  bytes_b = w->multipass ? up((size_t)4 * nrow * w->nb) : 0;
     const size_t bytes_ws = up((size_t)w->nw * sizeof(int2)), bytes_wp = up((size_t)w->nw * sizeof(double2));
-    w->nlinks = (n + 64 * PXL_UW1_U * PXL_UW1_WAVES - 1) / (64 * PXL_UW1_U * PXL_UW1_WAVES);
+    w->nlinks = (n + PXL_UW1_CHUNK - 1) / PXL_UW1_CHUNK;
     const size_t bytes_ln = up((size_t)w->nlinks * sizeof(UwLink) + 16);
     const size_t total = bytes_c + bytes_r + 2 * bytes_b + bytes_ws + bytes_wp + bytes_ln + 256;
     w->base = nullptr;

@@ -432,7 +432,7 @@ __global__ __launch_bounds__(64) void k_unwind_apply(SRC src, typename SRC::raw_
 // instructions instead of 48 B and ~215 for k_unwind_sums + k_unwind_apply (profiles/r04_unwind_counters.txt).  Out-of-place
 // calls only: a chunk needs the element just before it as the caller gave it, and the fallback needs the whole input untouched.
 //
-// One workgroup per chunk (PXL_UW1_WAVES waves of 64 * PXL_UW1_U points each); the rewound values stay in registers between the sum and the apply step.
+// One workgroup per chunk (PXL_UW1_WAVES waves of 64 * (PXL_UW1_U + PXL_UW1_UL) points each); the rewound values stay in registers and LDS between the sum and the apply step.
 //   1. chunk id = a ticket (atomic counter): every chunk with a smaller id has STARTED, and a started chunk publishes its
 //      aggregate before it waits for anything -- no wave ever waits for a wave that has not been dispatched
 //   2. m, the nominal increments, their sum T (per coordinate row) and "a NaN in this chunk"       -> link.agg
@@ -447,7 +447,10 @@ __global__ __launch_bounds__(64) void k_unwind_apply(SRC src, typename SRC::raw_
 // failure flag and publishes what it has, so every wave ends whatever happens; the flag sends the call to the fallback.
 // ------------------------------------------------------------------------------------------------
 #ifndef PXL_UW1_U
-#define PXL_UW1_U 4
+#define PXL_UW1_U 3            // 64-point groups per wave kept in registers
+#endif
+#ifndef PXL_UW1_UL
+#define PXL_UW1_UL 4           // ... and kept in LDS (first in the wave's run of points)
 #endif
 struct UwLink { unsigned long long agg, pre0, pre1, pad; };          // 32 bytes per chunk
 
@@ -458,40 +461,82 @@ __device__ inline unsigned long long uw_peek(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// PXL_UW1_WAVES waves of a workgroup share one chunk (64 * PXL_UW1_U points each, back to back) and ONE link: their sums meet in LDS
-// and only wave 0 walks the links.  (A first version gave every wave its own link: 195 000 links for 1e8 points, 5 000 of them
+// PXL_UW1_WAVES waves of a workgroup share one chunk (64 * (PXL_UW1_U + PXL_UW1_UL) points each, back to back) and ONE link: their sums
+// meet in LDS and only wave 0 walks the links.  (A first version gave every wave its own link: 195 000 links for 1e8 points, 5 000 of them
 // resident at once, and a wave that starts with all its predecessors still computing walks back through dozens of 64-link
 // windows -- 2.4 ms against the two-pass form's 1.05; profiles/r04_unwind_onepass.txt.  With 8 waves per link there are 16 times
 // fewer links, ~500 resident, and a look-back is a handful of windows: 0.93 ms; 16 waves of 256 points each: 0.88 ms.  Letting ALL
 // waves of the workgroup look back at once -- 1 024 links per round, windows combined through LDS -- was built and measured SLOWER
 // (1.10 ms: sixteen times the polling traffic and two workgroup barriers per round) and removed.)
+// Chunk size (round 4, late): the hand-over costs ~3.5 us per chunk whatever its size (0.175 of 0.855 ms at 4 096 points), so the
+// chunk should be as large as two workgroups per CU allow.  Registers hold 3 groups of 64 points per wave (60 VGPRs), LDS the 4
+// groups before them (17 B per point: 70 KB of the CU's 160 per workgroup): 7 168 points per link, 0.78-0.80 ms where the
+// 4 096-point chunk took 0.87 on the same box.  Other splits on that box: 4 + 4 (72 VGPRs: one workgroup per CU) 0.77-0.81,
+// 8 + 0 (80 VGPRs, one per CU) 0.80-0.82, 2 + 4 0.82, 3 + 3 0.80-0.82, 4 + 0 0.875 (tools/research/r04_24.sh).
 #ifndef PXL_UW1_WAVES
 #define PXL_UW1_WAVES 16
 #endif
+#ifndef PXL_UW1_CHUNK
+#define PXL_UW1_CHUNK (64LL * (PXL_UW1_U + PXL_UW1_UL) * PXL_UW1_WAVES)       // points per workgroup and link
+#endif
 #ifndef PXL_UW1_WIN
-#define PXL_UW1_WIN 1          // 64-link windows wave 0 reads per look-back round.  2 / 4 / 8 windows with their loads issued together cut
-#endif                         // the round trips but cost 12 VGPRs each (62 -> 74 / 84 / 126: the second 16-wave workgroup no longer fits a CU):
-                               // 0.89 / 0.98-1.01 / 1.03 / 1.23 ms per 1e8 points (round 4, one box)
+#define PXL_UW1_WIN 1          // 64-link windows wave 0 reads per look-back round.  More windows per round are slower whether or not the
+#endif                         // registers allow two workgroups per CU (more polling traffic): 1 / 2 / 3 windows 0.84 / 0.89-0.91 / 0.92-0.95 ms at
+                               // 46 / 54 / 63 VGPRs (4 096-point chunks, round 4, one box; tools/research/r04_23.sh)
+// The per-wave sums of a chunk, gathered by lanes 0..NW-1 and reduced in the wave: totals, the part before wave `upto`, and the
+// NaN flags likewise.  (An unrolled scalar loop over the LDS arrays keeps 3 NW values in flight in as many registers, and a
+// loop up to `wave` is a chain of LDS round trips.)
+struct UwGather { int tot[2], before[2]; unsigned int nan_all, nan_before; };
+template <int NW>
+__device__ inline UwGather uw_gather(const int (*wsum)[NW], const int* wnan, int lane, int upto) {
+    const bool in = lane < NW;
+    const int a0 = in ? wsum[0][lane] : 0, a1 = in ? wsum[1][lane] : 0;
+    const unsigned int na = in ? (unsigned)wnan[lane] : 0u;
+    const int s0 = uw_scan64(a0), s1 = uw_scan64(a1);
+    UwGather g;
+    g.tot[0] = __builtin_amdgcn_readlane(s0, 63); g.tot[1] = __builtin_amdgcn_readlane(s1, 63);
+    g.before[0] = upto > 0 ? __builtin_amdgcn_readlane(s0, upto - 1) : 0;
+    g.before[1] = upto > 0 ? __builtin_amdgcn_readlane(s1, upto - 1) : 0;
+    const unsigned long long n0 = __ballot(na & 1u), n1 = __ballot(na & 2u);
+    const unsigned long long below = (1ull << upto) - 1ull;                 // upto < 64
+    g.nan_all = (n0 ? 1u : 0u) | (n1 ? 2u : 0u);
+    g.nan_before = ((n0 & below) ? 1u : 0u) | ((n1 & below) ? 2u : 0u);
+    return g;
+}
+
 template <class SRC>
 __global__ __launch_bounds__(64 * PXL_UW1_WAVES) void k_unwind_onepass(SRC src, typename SRC::raw_t* out, int64_t n, UwLink* __restrict__ links,
                                                                        unsigned int* __restrict__ ticket, int32_t* __restrict__ flag) {
-    constexpr int U = PXL_UW1_U, NROW = SRC::NROW, NW = PXL_UW1_WAVES;
+    constexpr int U = PXL_UW1_U, UL = PXL_UW1_UL, NROW = SRC::NROW, NW = PXL_UW1_WAVES;
     __shared__ unsigned int id_s;
     __shared__ int wsum_s[2][NW], wnan_s[NW];
     __shared__ int excl_s[2];
     __shared__ unsigned int nanb_s, gaveup_s;
+    // the first UL groups of every wave wait in LDS between the sum and the apply step (17 B per point), the last U in registers
+    __shared__ double2 mL_s[UL > 0 ? UL : 1][64 * NW];
+    __shared__ unsigned char ccL_s[UL > 0 ? UL : 1][64 * NW];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x == 0) { id_s = atomicAdd(ticket, 1u); gaveup_s = 0u; }       // (taking blockIdx.x instead of a ticket: 0.845 vs 0.850 ms, not worth the dispatch-order assumption)
     __syncthreads();
     const int64_t id = (int64_t)id_s;
-    const int64_t base = (id * NW + wave) * 64 * U;
+    const int64_t base = (id * NW + wave) * 64 * (U + UL);
+    const int64_t baseR = base + 64 * UL;                                         // first point of the register groups
     const double P = src.period, rP = src.rperiod, ref = src.ref;
-    typename SRC::raw_t v[U];
+    typename SRC::raw_t vl[UL > 0 ? UL : 1], v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < UL; ++u) {
         const int64_t k = base + (int64_t)u * 64 + lane;
-        v[u] = (k < n) ? src.load(k) : src.zero();
+        vl[u] = (k < n) ? src.load(k) : src.zero();
+    }
+    // (the register groups' loads are issued one by one as the parked groups are consumed: U + UL loads in flight at once cost
+    // 16 more registers than two workgroups per CU leave)
+    if (UL == 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t k = baseR + (int64_t)u * 64 + lane;
+            v[u] = (k < n) ? src.load(k) : src.zero();
+        }
     }
     double mfirst[2];
     src.to_m((base > 0 && base - 1 < n) ? src.load(base - 1) : src.zero(), mfirst);
@@ -501,8 +546,28 @@ __global__ __launch_bounds__(64 * PXL_UW1_WAVES) void k_unwind_onepass(SRC src, 
     int sum[2] = {0, 0};
     bool nanl[2] = {false, false};
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < UL; ++u) {
         const int64_t k = base + (int64_t)u * 64 + lane;
+        double mm[2], mp[2];
+        int c[2] = {0, 0};
+        uw_element(src, lane, k, k < n, vl[u], mlast, mm, mp, c);
+        mL_s[u][threadIdx.x] = make_double2(mm[0], mm[1]);
+        ccL_s[u][threadIdx.x] = (unsigned char)((c[0] + 1) | (NROW == 2 ? (c[1] + 1) << 2 : 0));
+#pragma unroll
+        for (int r = 0; r < NROW; ++r) {
+            sum[r] += c[r];
+            nanl[r] = nanl[r] || (k < n && mm[r] != mm[r]);
+            mlast[r] = uw_lane63(mm[r]);
+        }
+#pragma unroll
+        for (int u2 = u * U / UL; u2 < (u + 1) * U / UL; ++u2) {           // this group's share of the register groups' loads
+            const int64_t k2 = baseR + (int64_t)u2 * 64 + lane;
+            v[u2] = (k2 < n) ? src.load(k2) : src.zero();
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t k = baseR + (int64_t)u * 64 + lane;
         double mp[2];
         int c[2] = {0, 0};
         uw_element(src, lane, k, k < n, v[u], mlast, m[u], mp, c);
@@ -521,12 +586,11 @@ __global__ __launch_bounds__(64 * PXL_UW1_WAVES) void k_unwind_onepass(SRC src, 
     }
     __syncthreads();
     if (wave == 0) {
-        int T[2] = {0, 0};
-        unsigned int nan_here = 0;
-#pragma unroll
-        for (int w2 = 0; w2 < NW; ++w2) { T[0] += wsum_s[0][w2]; T[1] += wsum_s[1][w2]; nan_here |= (unsigned)wnan_s[w2]; }
-        // 2. the aggregate: |T| <= 64 U NW = 4096 fits 14 bits with its offset
-        if (lane == 0) uw_publish(&links[id].agg, (unsigned)(T[0] + 8192) | ((unsigned)(T[1] + 8192) << 14) | (nan_here << 28), 1u);
+        const UwGather gt = uw_gather<NW>(wsum_s, wnan_s, lane, 0);
+        const int T[2] = {gt.tot[0], gt.tot[1]};
+        const unsigned int nan_here = gt.nan_all;
+        // 2. the aggregate: |T| <= 64 U NW (at most 15 360 for U = 15) fits 15 bits with its offset; two NaN bits on top
+        if (lane == 0) uw_publish(&links[id].agg, (unsigned)(T[0] + 16384) | ((unsigned)(T[1] + 16384) << 15) | (nan_here << 30), 1u);
         // 3. look-back
         int E[2] = {0, 0};
         unsigned int nan_before = 0;
@@ -563,7 +627,7 @@ __global__ __launch_bounds__(64 * PXL_UW1_WAVES) void k_unwind_onepass(SRC src, 
                     unsigned int nb = 0;
                     if (j >= 0 && lane < first) {
                         const unsigned int pa = (unsigned)(a[wdw] >> 32);
-                        c0 = (int)(pa & 0x3fffu) - 8192; c1 = (int)((pa >> 14) & 0x3fffu) - 8192; nb = pa >> 28;
+                        c0 = (int)(pa & 0x7fffu) - 16384; c1 = (int)((pa >> 15) & 0x7fffu) - 16384; nb = pa >> 30;
                     } else if (j >= 0 && lane == first) {
                         c0 = (int)(unsigned)(p0[wdw] >> 32); c1 = (int)(unsigned)(p1[wdw] >> 32);
                         nb = (((unsigned)p0[wdw] >> 1) & 1u) | ((((unsigned)p1[wdw] >> 1) & 1u) << 1);
@@ -595,46 +659,53 @@ __global__ __launch_bounds__(64 * PXL_UW1_WAVES) void k_unwind_onepass(SRC src, 
         }
     }
     __syncthreads();
-    // 5. apply: k_unwind_apply's arithmetic on the values kept in registers
-    int carry[2] = {excl_s[0], excl_s[1]};
-    unsigned int nan_before = nanb_s;
-    for (int w2 = 0; w2 < wave; ++w2) { carry[0] += wsum_s[0][w2]; carry[1] += wsum_s[1][w2]; nan_before |= (unsigned)wnan_s[w2]; }
+    // 5. apply: k_unwind_apply's arithmetic on the values kept in LDS and in registers
+    const UwGather gi = uw_gather<NW>(wsum_s, wnan_s, lane, wave);
+    int carry[2] = {excl_s[0] + gi.before[0], excl_s[1] + gi.before[1]};
+    const unsigned int nan_before = nanb_s | gi.nan_before;
     bool pex[2] = {(nan_before & 1u) != 0, (nan_before & 2u) != 0};
     bool bad = gaveup_s != 0u;
     mlast[0] = mfirst[0]; mlast[1] = mfirst[1];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int64_t k = base + (int64_t)u * 64 + lane;
+    auto apply_group = [&](int64_t k, const double* mv, int ccv) {
         const bool valid = k < n;
-        const int s = uw_scan64(cc[u]);
+        const int s = uw_scan64(ccv);
         const int tot = __builtin_amdgcn_readlane(s, 63);
         double y[2] = {0.0, 0.0};
 #pragma unroll
         for (int r = 0; r < NROW; ++r) {
-            const double mp = uw_shr1_first(m[u][r], mlast[r]);
-            mlast[r] = uw_lane63(m[u][r]);
+            const double mp = uw_shr1_first(mv[r], mlast[r]);
+            mlast[r] = uw_lane63(mv[r]);
             const int field = r == 0 ? (s & 0xffff) : (s >> 16);
-            const int c = (r == 0 ? (cc[u] & 0xffff) : (cc[u] >> 16)) - 1;
+            const int c = (r == 0 ? (ccv & 0xffff) : (ccv >> 16)) - 1;
             const int rr = carry[r] + field - (lane + 1);            // r_k
             carry[r] += (r == 0 ? (tot & 0xffff) : (tot >> 16)) - 64;
-            const unsigned long long nanmask = __ballot(valid && m[u][r] != m[u][r]);
+            const unsigned long long nanmask = __ballot(valid && mv[r] != mv[r]);
             const bool poisoned = pex[r] || (nanmask & ((2ull << lane) - 1ull)) != 0ull;
             pex[r] = pex[r] || nanmask != 0ull;
             if (!valid) continue;
             if (poisoned) { y[r] = __builtin_nan("") + ref; continue; }
             if (k > 0) {
                 const double yprev = mp - (double)(rr - c) * P;       // y[k-1] as the reference forms it
-                const double a = m[u][r] - yprev;
+                const double a = mv[r] - yprev;
                 const double qa = a * rP;
                 if (!(fabs(qa - (double)rr) < 0.4999)) {
                     const double q = a / P;
                     if (!(rint(q) == (double)rr)) bad = true;
                 }
             }
-            y[r] = (m[u][r] - (double)(k > 0 ? rr : 0) * P) + ref;     // k = 0: m - 0 = m, bit for bit
+            y[r] = (mv[r] - (double)(k > 0 ? rr : 0) * P) + ref;     // k = 0: m - 0 = m, bit for bit
         }
         if (valid) SRC::store(out, k, y);
+    };
+#pragma unroll
+    for (int u = 0; u < UL; ++u) {
+        const double2 mm = mL_s[u][threadIdx.x];
+        const int cb = (int)ccL_s[u][threadIdx.x];
+        const double mv[2] = {mm.x, mm.y};
+        apply_group(base + (int64_t)u * 64 + lane, mv, (cb & 3) | ((cb >> 2) << 16));
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u) apply_group(baseR + (int64_t)u * 64 + lane, m[u], cc[u]);
     if (__any(bad) && lane == 0) atomicOr(flag, 1);
 }
 

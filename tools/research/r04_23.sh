@@ -1,0 +1,13 @@
+#!/bin/bash
+# one-pass unwind after the lane-parallel gather (62 -> 46 VGPRs): look-back windows per round and chunk size revisited
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$R/gpurun_out/r04_uw3
+mkdir -p $out
+cd $R
+timeout -k 10 400 python3 -m pytest tests -m gpu -x -q -k "unwind or pix2sky or soa or safe" > $out/tests.txt 2>&1; rc=$?; tail -3 $out/tests.txt; [ $rc -eq 0 ] || exit $rc
+for rep in 1 2; do
+echo "== WIN1 U4 (tree)  $(timeout -k 10 120 python3 tools/prof_unwind.py 2>&1 | grep out-of | tail -2 | tr '\n' ' ')"
+for v in w2 w3 u5 w2u5 u6; do
+echo "== $v  $(PXL_LIB_PATH=$R/variants/lib_$v.so timeout -k 10 120 python3 tools/prof_unwind.py 2>&1 | grep out-of | tail -2 | tr '\n' ' ')"
+done; done
+for v in w2 w2u5; do PXL_LIB_PATH=$R/variants/lib_$v.so timeout -k 10 400 python3 -m pytest tests -m gpu -x -q -k "unwind" 2>&1 | tail -1; done
