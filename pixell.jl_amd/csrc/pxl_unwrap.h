@@ -1,5 +1,6 @@
 // pxl_unwrap.h -- unwind! as a verified integer scan, the exact serial fallback, and rewind!; included by pxl_kernels.hip (one translation unit, -ffp-contract=off).
 #pragma once
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------------
 // unwind! (A8, car_proj.jl:110-112 -> enmap_ops.jl:26-32): rewind, subtract ref, DSP.unwrap along the
@@ -274,10 +275,12 @@ __device__ inline void uw_element(const SRC& s, int lane, int64_t k, bool valid,
 #pragma unroll
     for (int r = 0; r < SRC::NROW; ++r) {
         mp[r] = uw_shr1_first(m[r], mlast[r]);
-        const double d = (m[r] - mp[r]) * s.rperiod;               // |d| <= 1 for rewound values
-        // clamped BEFORE the conversion (rint is monotone, so this is clamp(rint(d), -1, 1)): the 16-bit scan fields stay consistent
-        // whatever d was, and a NaN becomes -1 -- every element from the first NaN of a row on is written as NaN whatever its count
-        const int g = (int)rint(fmin(fmax(d, -1.0), 1.0));
+        // round((m - mp) / P) for rewound values (|m - mp| < P) is +1 above half a period, -1 below minus half, else 0 (a tie rounds
+        // to the even 0): two compares instead of multiply, clamp, rint and convert.  Always within {-1, 0, 1}, so the 16-bit scan
+        // fields stay consistent whatever the input; a NaN gives 0 -- every element from the first NaN of a row on is written as
+        // NaN whatever its count.
+        const double d = m[r] - mp[r], half = s.period / 2;
+        const int g = (d > half ? 1 : 0) - (d < -half ? 1 : 0);
         c[r] = (valid && k > 0) ? g : 0;
     }
 }
@@ -579,10 +582,10 @@ __global__ __launch_bounds__(64 * PXL_UW1_WAVES) void k_unwind_onepass(SRC src, 
             mlast[r] = uw_lane63(m[u][r]);
         }
     }
+    const unsigned int nh_wave = (__ballot(nanl[0]) != 0ull ? 1u : 0u) | (NROW == 2 && __ballot(nanl[1]) != 0ull ? 2u : 0u);
     {
         int T0 = uw_wave_total(sum[0]), T1 = NROW == 2 ? uw_wave_total(sum[1]) : 0;
-        unsigned int nh = (__ballot(nanl[0]) != 0ull ? 1u : 0u) | (NROW == 2 && __ballot(nanl[1]) != 0ull ? 2u : 0u);
-        if (lane == 0) { wsum_s[0][wave] = T0; wsum_s[1][wave] = T1; wnan_s[wave] = (int)nh; }
+        if (lane == 0) { wsum_s[0][wave] = T0; wsum_s[1][wave] = T1; wnan_s[wave] = (int)nh_wave; }
     }
     __syncthreads();
     if (wave == 0) {
@@ -659,53 +662,62 @@ __global__ __launch_bounds__(64 * PXL_UW1_WAVES) void k_unwind_onepass(SRC src, 
         }
     }
     __syncthreads();
-    // 5. apply: k_unwind_apply's arithmetic on the values kept in LDS and in registers
+    // 5. apply: k_unwind_apply's arithmetic on the values kept in LDS and in registers.  y' = m - r P of the element before (the
+    // reference's y[k-1]) is taken from the neighbouring lane's own result instead of being formed a second time from its m.
     const UwGather gi = uw_gather<NW>(wsum_s, wnan_s, lane, wave);
     int carry[2] = {excl_s[0] + gi.before[0], excl_s[1] + gi.before[1]};
     const unsigned int nan_before = nanb_s | gi.nan_before;
     bool pex[2] = {(nan_before & 1u) != 0, (nan_before & 2u) != 0};
     bool bad = gaveup_s != 0u;
-    mlast[0] = mfirst[0]; mlast[1] = mfirst[1];
-    auto apply_group = [&](int64_t k, const double* mv, int ccv) {
+    double ylast[2] = {mfirst[0] - (double)carry[0] * P, mfirst[1] - (double)carry[1] * P};       // y' of the element before this wave's first
+    auto apply_group = [&](auto nonan_tag, int64_t k, const double* mv, int ccv) {
+        constexpr bool NONAN = decltype(nonan_tag)::value;          // no NaN in this wave's points or before them: no poison bookkeeping
         const bool valid = k < n;
         const int s = uw_scan64(ccv);
         const int tot = __builtin_amdgcn_readlane(s, 63);
         double y[2] = {0.0, 0.0};
 #pragma unroll
         for (int r = 0; r < NROW; ++r) {
-            const double mp = uw_shr1_first(mv[r], mlast[r]);
-            mlast[r] = uw_lane63(mv[r]);
             const int field = r == 0 ? (s & 0xffff) : (s >> 16);
-            const int c = (r == 0 ? (ccv & 0xffff) : (ccv >> 16)) - 1;
-            const int rr = carry[r] + field - (lane + 1);            // r_k
+            const int rr = carry[r] + field - (lane + 1);            // r_k (0 at k = 0: no carry, increment forced to 0)
             carry[r] += (r == 0 ? (tot & 0xffff) : (tot >> 16)) - 64;
-            const unsigned long long nanmask = __ballot(valid && mv[r] != mv[r]);
-            const bool poisoned = pex[r] || (nanmask & ((2ull << lane) - 1ull)) != 0ull;
-            pex[r] = pex[r] || nanmask != 0ull;
+            const double rrd = (double)rr;
+            const double yq = mv[r] - rrd * P;                       // y[k] before ref is added; k = 0: m - 0 = m, bit for bit
+            const double yprev = uw_shr1_first(yq, ylast[r]);        // y[k-1] as the reference forms it
+            ylast[r] = uw_lane63(yq);
+            bool poisoned = false;
+            if (!NONAN) {
+                const unsigned long long nanmask = __ballot(valid && mv[r] != mv[r]);
+                poisoned = pex[r] || (nanmask & ((2ull << lane) - 1ull)) != 0ull;
+                pex[r] = pex[r] || nanmask != 0ull;
+            }
             if (!valid) continue;
             if (poisoned) { y[r] = __builtin_nan("") + ref; continue; }
             if (k > 0) {
-                const double yprev = mp - (double)(rr - c) * P;       // y[k-1] as the reference forms it
                 const double a = mv[r] - yprev;
                 const double qa = a * rP;
-                if (!(fabs(qa - (double)rr) < 0.4999)) {
+                if (!(fabs(qa - rrd) < 0.4999)) {
                     const double q = a / P;
-                    if (!(rint(q) == (double)rr)) bad = true;
+                    if (!(rint(q) == rrd)) bad = true;
                 }
             }
-            y[r] = (mv[r] - (double)(k > 0 ? rr : 0) * P) + ref;     // k = 0: m - 0 = m, bit for bit
+            y[r] = yq + ref;
         }
         if (valid) SRC::store(out, k, y);
     };
+    auto apply_all = [&](auto nonan_tag) {
 #pragma unroll
-    for (int u = 0; u < UL; ++u) {
-        const double2 mm = mL_s[u][threadIdx.x];
-        const int cb = (int)ccL_s[u][threadIdx.x];
-        const double mv[2] = {mm.x, mm.y};
-        apply_group(base + (int64_t)u * 64 + lane, mv, (cb & 3) | ((cb >> 2) << 16));
-    }
+        for (int u = 0; u < UL; ++u) {
+            const double2 mm = mL_s[u][threadIdx.x];
+            const int cb = (int)ccL_s[u][threadIdx.x];
+            const double mv[2] = {mm.x, mm.y};
+            apply_group(nonan_tag, base + (int64_t)u * 64 + lane, mv, (cb & 3) | ((cb >> 2) << 16));
+        }
 #pragma unroll
-    for (int u = 0; u < U; ++u) apply_group(baseR + (int64_t)u * 64 + lane, m[u], cc[u]);
+        for (int u = 0; u < U; ++u) apply_group(nonan_tag, baseR + (int64_t)u * 64 + lane, m[u], cc[u]);
+    };
+    if ((nan_before | nh_wave) == 0u) apply_all(std::true_type{});
+    else apply_all(std::false_type{});
     if (__any(bad) && lane == 0) atomicOr(flag, 1);
 }
 
