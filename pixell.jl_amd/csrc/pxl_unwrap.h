@@ -526,19 +526,23 @@ __global__ __launch_bounds__(64 * PXL_UW1_WAVES) void k_unwind_onepass(SRC src, 
     const int64_t base = (id * NW + wave) * 64 * (U + UL);
     const int64_t baseR = base + 64 * UL;                                         // first point of the register groups
     const double P = src.period, rP = src.rperiod, ref = src.ref;
+    // this wave's points are base + idx, idx < nvalid (32-bit tests instead of 64-bit ones per group); kpos: none of them is the batch's first
+    const int64_t left = n - base;
+    const int nvalid = left <= 0 ? 0 : (left >= 64 * (U + UL) ? 64 * (U + UL) : (int)left);
+    const bool kpos = base > 0;
     typename SRC::raw_t vl[UL > 0 ? UL : 1], v[U];
 #pragma unroll
     for (int u = 0; u < UL; ++u) {
-        const int64_t k = base + (int64_t)u * 64 + lane;
-        vl[u] = (k < n) ? src.load(k) : src.zero();
+        const int idx = u * 64 + lane;
+        vl[u] = (idx < nvalid) ? src.load(base + idx) : src.zero();
     }
     // (the register groups' loads are issued one by one as the parked groups are consumed: U + UL loads in flight at once cost
     // 16 more registers than two workgroups per CU leave)
     if (UL == 0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t k = baseR + (int64_t)u * 64 + lane;
-            v[u] = (k < n) ? src.load(k) : src.zero();
+            const int idx = u * 64 + lane;
+            v[u] = (idx < nvalid) ? src.load(base + idx) : src.zero();
         }
     }
     double mfirst[2];
@@ -550,35 +554,37 @@ __global__ __launch_bounds__(64 * PXL_UW1_WAVES) void k_unwind_onepass(SRC src, 
     bool nanl[2] = {false, false};
 #pragma unroll
     for (int u = 0; u < UL; ++u) {
-        const int64_t k = base + (int64_t)u * 64 + lane;
+        const int idx = u * 64 + lane;
+        const bool valid = idx < nvalid;
         double mm[2], mp[2];
         int c[2] = {0, 0};
-        uw_element(src, lane, k, k < n, vl[u], mlast, mm, mp, c);
+        uw_element(src, lane, (int64_t)((kpos || idx > 0) ? 1 : 0), valid, vl[u], mlast, mm, mp, c);      // uw_element only asks whether k > 0
         mL_s[u][threadIdx.x] = make_double2(mm[0], mm[1]);
         ccL_s[u][threadIdx.x] = (unsigned char)((c[0] + 1) | (NROW == 2 ? (c[1] + 1) << 2 : 0));
 #pragma unroll
         for (int r = 0; r < NROW; ++r) {
             sum[r] += c[r];
-            nanl[r] = nanl[r] || (k < n && mm[r] != mm[r]);
+            nanl[r] = nanl[r] || (valid && mm[r] != mm[r]);
             mlast[r] = uw_lane63(mm[r]);
         }
 #pragma unroll
         for (int u2 = u * U / UL; u2 < (u + 1) * U / UL; ++u2) {           // this group's share of the register groups' loads
-            const int64_t k2 = baseR + (int64_t)u2 * 64 + lane;
-            v[u2] = (k2 < n) ? src.load(k2) : src.zero();
+            const int idx2 = (UL + u2) * 64 + lane;
+            v[u2] = (idx2 < nvalid) ? src.load(base + idx2) : src.zero();
         }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int64_t k = baseR + (int64_t)u * 64 + lane;
+        const int idx = (UL + u) * 64 + lane;
+        const bool valid = idx < nvalid;
         double mp[2];
         int c[2] = {0, 0};
-        uw_element(src, lane, k, k < n, v[u], mlast, m[u], mp, c);
+        uw_element(src, lane, (int64_t)((kpos || idx > 0) ? 1 : 0), valid, v[u], mlast, m[u], mp, c);
         cc[u] = (c[0] + 1) | (NROW == 2 ? (c[1] + 1) << 16 : 0);
 #pragma unroll
         for (int r = 0; r < NROW; ++r) {
             sum[r] += c[r];
-            nanl[r] = nanl[r] || (k < n && m[u][r] != m[u][r]);
+            nanl[r] = nanl[r] || (valid && m[u][r] != m[u][r]);
             mlast[r] = uw_lane63(m[u][r]);
         }
     }
@@ -671,8 +677,9 @@ __global__ __launch_bounds__(64 * PXL_UW1_WAVES) void k_unwind_onepass(SRC src, 
     bool bad = gaveup_s != 0u;
     double ylast[2] = {mfirst[0] - (double)carry[0] * P, mfirst[1] - (double)carry[1] * P};       // y' of the element before this wave's first
     auto apply_group = [&](auto nonan_tag, int64_t k, const double* mv, int ccv) {
-        constexpr bool NONAN = decltype(nonan_tag)::value;          // no NaN in this wave's points or before them: no poison bookkeeping
-        const bool valid = k < n;
+        // the plain case: no NaN in this wave's points or before them (no poison bookkeeping), every point exists, none is the first
+        constexpr bool NONAN = decltype(nonan_tag)::value, FULL = NONAN;
+        const bool valid = FULL || k < n;
         const int s = uw_scan64(ccv);
         const int tot = __builtin_amdgcn_readlane(s, 63);
         double y[2] = {0.0, 0.0};
@@ -693,7 +700,7 @@ __global__ __launch_bounds__(64 * PXL_UW1_WAVES) void k_unwind_onepass(SRC src, 
             }
             if (!valid) continue;
             if (poisoned) { y[r] = __builtin_nan("") + ref; continue; }
-            if (k > 0) {
+            if (FULL || k > 0) {
                 const double a = mv[r] - yprev;
                 const double qa = a * rP;
                 if (!(fabs(qa - rrd) < 0.4999)) {
@@ -716,7 +723,7 @@ __global__ __launch_bounds__(64 * PXL_UW1_WAVES) void k_unwind_onepass(SRC src, 
 #pragma unroll
         for (int u = 0; u < U; ++u) apply_group(nonan_tag, baseR + (int64_t)u * 64 + lane, m[u], cc[u]);
     };
-    if ((nan_before | nh_wave) == 0u) apply_all(std::true_type{});
+    if ((nan_before | nh_wave) == 0u && base > 0 && base + 64 * (U + UL) <= n) apply_all(std::true_type{});
     else apply_all(std::false_type{});
     if (__any(bad) && lane == 0) atomicOr(flag, 1);
 }
