@@ -218,6 +218,21 @@ int pxl_reproject_generic_bilinear_f64(const pxl_car_wcs* wcs_in, int proj_in, c
                                        const double* src, const pxl_car_wcs* wcs_out, int proj_out,
                                        const int64_t shape_out[2], double* dst, void* stream);
 
+/* The same operator with its coordinate lattice kept: what pxl_reproject_plan is to the separable CAR -> CAR path.  Creating
+ * the plan evaluates every tile's lattice and check points once (k_generic_lattice) and records which tiles must be evaluated
+ * per pixel; executing it is the pixel kernel alone (plus the per-pixel launch only when such tiles exist), on any source map
+ * of the plan's input geometry with any number of components.  A mosaic of patches, or many maps onto one patch, pays the
+ * transcendental part once per geometry pair.  Same results as the one-shot entry, bit for bit (same kernels, same lattice).
+ * create synchronises `stream` (it reads the count of per-pixel tiles back); execute is asynchronous on its stream.
+ * 2.8 MB of device memory per 4096 x 4096 output patch (676 B per tile), owned by the plan.                           */
+typedef struct pxl_generic_plan pxl_generic_plan;
+int pxl_generic_plan_create(const pxl_car_wcs* wcs_in, int proj_in, const int64_t shape_in[2],
+                            const pxl_car_wcs* wcs_out, int proj_out, const int64_t shape_out[2],
+                            void* stream, pxl_generic_plan** plan);
+int pxl_generic_plan_execute(const pxl_generic_plan* plan, int64_t ncomp, const double* src, double* dst, void* stream);
+int pxl_generic_plan_tiles(const pxl_generic_plan* plan, int64_t* exact_tiles, int64_t* total_tiles);
+int pxl_generic_plan_destroy(pxl_generic_plan* plan);
+
 /* diagnostics: of the 128 x 32 output tiles of the last pxl_reproject_generic_bilinear_f64 call on the current device,
  * how many evaluated the coordinates per pixel (the interpolant failed its 1e-10-pixel check there: the rewind jump of
  * a periodic source, the Gnomonic horizon, very coarse pixels).  Synchronises `stream`.                          */

@@ -219,6 +219,36 @@ function reproject_generic(m::Enmap{Float64,N,<:HIPArray}, shape_out::Tuple{Int,
     return Enmap(out, wcs_out)
 end
 
+# ---- the same with the coordinate lattice kept (pxl_generic_plan_*): make once per pair of geometries, execute per map
+mutable struct GenericReprojectPlan
+    handle::Ptr{Cvoid}
+    shape_in::NTuple{2,Int}
+    shape_out::NTuple{2,Int}
+    wcs_out::AnyFastWCS
+    function GenericReprojectPlan(shape_in, wcs_in::AnyFastWCS, shape_out, wcs_out::AnyFastWCS)
+        shp_in, shp_out = Int64[shape_in[1], shape_in[2]], Int64[shape_out[1], shape_out[2]]
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        GC.@preserve shp_in shp_out check(ccall((:pxl_generic_plan_create, libpixell_hip), Cint,
+            (Ref{CarWCS}, Cint, Ptr{Int64}, Ref{CarWCS}, Cint, Ptr{Int64}, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}),
+            CarWCS(wcs_in), projcode(wcs_in), shp_in, CarWCS(wcs_out), projcode(wcs_out), shp_out, NULLSTREAM, h))
+        p = new(h[], (shape_in[1], shape_in[2]), (shape_out[1], shape_out[2]), wcs_out)
+        finalizer(x -> ccall((:pxl_generic_plan_destroy, libpixell_hip), Cint, (Ptr{Cvoid},), x.handle), p)
+    end
+end
+function generic_plan_tiles(plan::GenericReprojectPlan)
+    ex, tot = Ref{Int64}(0), Ref{Int64}(0)
+    check(ccall((:pxl_generic_plan_tiles, libpixell_hip), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}), plan.handle, ex, tot))
+    return ex[], tot[]
+end
+function reproject!(dst::HIPArray{Float64}, plan::GenericReprojectPlan, src::HIPArray{Float64})
+    nc = ndims(src) == 3 ? size(src, 3) : 1
+    (size(src, 1), size(src, 2)) == plan.shape_in || error("reproject!: source is $(size(src)), plan expects $(plan.shape_in)")
+    length(dst) == nc * prod(plan.shape_out) || error("reproject!: destination has $(length(dst)) elements")
+    GC.@preserve src dst check(ccall((:pxl_generic_plan_execute, libpixell_hip), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cvoid}), plan.handle, nc, src.ptr, dst.ptr, NULLSTREAM))
+    return dst
+end
+
 # ---- a kept reprojection plan (coordinate tables live on the device): create once, execute per map.
 #      Float64 and Float32 storage; windows (row0, nrows) describe declination strips of a sharded map.
 mutable struct ReprojectPlan
@@ -529,6 +559,6 @@ function place_pair(::Type{T}, src_dims::NTuple{N,Int}, dst_dims::NTuple{M,Int};
 end
 
 export mem_probe_pair, map_classes, place_pair, place_pair_native, MemPair, MemPlacedInfo, ALLOC_POLICY
-export HIPArray, posmap_device, reproject, reproject_generic, reproject!, ReprojectPlan, sample_bilinear, SamplePairs, HaloXfer, sharded_step!
+export HIPArray, posmap_device, reproject, reproject_generic, reproject!, ReprojectPlan, GenericReprojectPlan, generic_plan_tiles, sample_bilinear, SamplePairs, HaloXfer, sharded_step!
 export PxlComm, comm_unique_id, comm_init_rank, comm_destroy, comm_backend
 end # module

@@ -119,6 +119,10 @@ end
     tan = Pixell.Gnomonic{Float64}((-1 / 6, 1 / 6), (128.5, 128.5), (30.0, 10.0), π / 180)
     patch = PixellHIP.reproject(m, (256, 256), tan)                     # picked by dispatch on the Gnomonic output WCS
     @test maximum(abs.(Array(parent(patch)) .- 1)) < 1e-12
+    plan = PixellHIP.GenericReprojectPlan(shape, wcs, (256, 256), tan)     # the lattice kept: same bits as the one-shot call
+    kept = PixellHIP.reproject!(HIPArray{Float64}(undef, 256, 256), plan, parent(m))
+    @test Array(kept) == Array(parent(patch))
+    @test PixellHIP.generic_plan_tiles(plan) == (0, 2 * 8)                 # 128 x 32 tiles, none evaluated per pixel
     back = PixellHIP.reproject(patch, shape, wcs)                       # Gnomonic -> CAR: ones inside the patch, zeros outside
     @test all(x -> abs(x) < 1e-12 || abs(x - 1) < 1e-9 || 0 <= x <= 1, Array(parent(back)))
     ang = 40 .* rand(2, 10_000) .- 20

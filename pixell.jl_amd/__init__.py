@@ -13,7 +13,7 @@ from .wcs import (AbstractCARWCS, CarClenshawCurtis, CarFejer1, Gnomonic, SkyBou
 from .geometry import (JlRange, create_car_wcs, extent_cyl, fullsky_geometry, geometry, laxes_cyl, pad_geometry,
                        skyarea, slice_geometry)
 from .enmap import Enmap, NoWCS, getwcs
-from .ops import (ReprojectPlan, SamplePairs, fill_random_, fill_sphere_points_, pix2sky, pix2sky_, pix2sky_rewind,
+from .ops import (GenericReprojectPlan, ReprojectPlan, SamplePairs, fill_random_, fill_sphere_points_, pix2sky, pix2sky_, pix2sky_rewind,
                   pixareamap, pixareamap_, posmap, reproject, rewind_, sample_bilinear, sky2pix, sky2pix_,
                   sky2pix_broadcast, unwind_)
 from .sharding import DecStripLayout, DecStripReprojector, strip_bounds

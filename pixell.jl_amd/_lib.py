@@ -67,6 +67,10 @@ SIGNATURES = {
     "pxl_reproject_car_bilinear_f64": (C.c_int, [_WP, _SHP, _P, _WP, _SHP, _P, _P]),
     "pxl_reproject_generic_bilinear_f64": (C.c_int, [_WP, C.c_int, _SHP, _P, _WP, C.c_int, _SHP, _P, _P]),
     "pxl_reproject_generic_last_tiles": (C.c_int, [C.POINTER(_I64), C.POINTER(_I64), _P]),
+    "pxl_generic_plan_create": (C.c_int, [_WP, C.c_int, _SHP, _WP, C.c_int, _SHP, _P, C.POINTER(_P)]),
+    "pxl_generic_plan_execute": (C.c_int, [_P, _I64, _P, _P, _P]),
+    "pxl_generic_plan_tiles": (C.c_int, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
+    "pxl_generic_plan_destroy": (C.c_int, [_P]),
     "pxl_sample_car_bilinear_f64": (C.c_int, [_WP, _SHP, _P, _I64, _I64, _I64, _P, _P, _P]),
     "pxl_sample_car_bilinear_f32": (C.c_int, [_WP, _SHP, _P, _I64, _I64, _I64, _P, _P, _P]),
     "pxl_sample_pairs_elems": (_I64, [_SHP, _I64]),

@@ -1128,20 +1128,18 @@ int pxl_reproject_generic_last_tiles(int64_t* exact_tiles, int64_t* total_tiles,
     return PXL_OK;
 }
 
-int pxl_reproject_generic_bilinear_f64(const pxl_car_wcs* wcs_in, int proj_in, const int64_t shape_in[3],
-                                       const double* src, const pxl_car_wcs* wcs_out, int proj_out,
-                                       const int64_t shape_out[2], double* dst, void* stream) {
-    if (!wcs_ok(wcs_in) || !wcs_ok(wcs_out)) return fail(PXL_EINVAL, "reproject_generic: invalid WCS");
-    if (!shape_in || !shape_out) return fail(PXL_EINVAL, "reproject_generic: null shape");
-    if (shape_in[0] < 1 || shape_in[1] < 1 || shape_in[2] < 1 || shape_out[0] < 1 || shape_out[1] < 1)
-        return fail(PXL_EINVAL, "reproject_generic: shapes must be positive");
+// geometry part of GenericParams (everything but the buffers and the component count)
+static int generic_params(const char* who, const pxl_car_wcs* wcs_in, int proj_in, const int64_t* shape_in,
+                          const pxl_car_wcs* wcs_out, int proj_out, const int64_t* shape_out, GenericParams* out) {
+    if (!wcs_ok(wcs_in) || !wcs_ok(wcs_out)) return fail(PXL_EINVAL, "%s: invalid WCS", who);
+    if (!shape_in || !shape_out) return fail(PXL_EINVAL, "%s: null shape", who);
+    if (shape_in[0] < 1 || shape_in[1] < 1 || shape_out[0] < 1 || shape_out[1] < 1)
+        return fail(PXL_EINVAL, "%s: shapes must be positive", who);
     if ((proj_in != PXL_PROJ_CAR && proj_in != PXL_PROJ_TAN) || (proj_out != PXL_PROJ_CAR && proj_out != PXL_PROJ_TAN))
-        return fail(PXL_EINVAL, "reproject_generic: unknown projection code");
-    if (!src || !dst) return fail(PXL_EINVAL, "reproject_generic: null src/dst");
+        return fail(PXL_EINVAL, "%s: unknown projection code", who);
     GenericParams p;
     memset(&p, 0, sizeof(p));
-    p.src = src; p.dst = dst;
-    p.nx = shape_in[0]; p.ny = shape_in[1]; p.nc = (int32_t)shape_in[2];
+    p.nx = shape_in[0]; p.ny = shape_in[1]; p.nc = 1;
     p.nxo = shape_out[0]; p.nyo = shape_out[1];
     p.proj_in = proj_in; p.proj_out = proj_out;
     p.periodic = (proj_in == PXL_PROJ_CAR) &&
@@ -1149,6 +1147,101 @@ int pxl_reproject_generic_bilinear_f64(const pxl_car_wcs* wcs_in, int proj_in, c
     if (proj_out == PXL_PROJ_TAN) p.out_tan = tan_setup(*wcs_out); else p.out_car = car_affine(*wcs_out);
     if (proj_in == PXL_PROJ_TAN) p.in_tan = tan_setup(*wcs_in);
     else p.in_car = sky2pix_setup(*wcs_in, p.nx, p.ny, 1, PXL_FORM_DIV);
+    *out = p;
+    return PXL_OK;
+}
+static void launch_generic_pixels(const GenericParams& p, int64_t gx, int64_t gy, const double2* lat, const int32_t* flag, hipStream_t st) {
+    // PXL_GENERIC_V=1: round 3's pixel kernel (one pixel per lane, 8-byte taps, ~99 VALU per pixel), kept for A/B; default: the lean
+    // round-4 form.  (Two more forms were built, measured slower and moved to tools/research/: two pixels per lane, the LDS ring.)
+    if (env_int("PXL_GENERIC_V", 3) == 1 || env_int("PXL_GENERIC_V1", 0))
+        hipLaunchKernelGGL(k_reproject_generic_tiled, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, lat, flag);
+    else
+        hipLaunchKernelGGL(k_reproject_generic_tiled3, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, lat, flag);
+}
+
+// ---- the generic operator with its lattice kept (include/pixell_hip.h)
+struct pxl_generic_plan {
+    GenericParams p;             // geometry; src / dst / nc are filled per execute
+    int64_t gx, gy, ntiles, exact;
+    char* ws;                    // lattice (ntiles x 42 coordinate pairs) + flags (ntiles x int32) + the counter of flagged tiles
+    double2* lat; int32_t* flag; unsigned int* counter;
+    int device;
+};
+
+int pxl_generic_plan_create(const pxl_car_wcs* wcs_in, int proj_in, const int64_t shape_in[2],
+                            const pxl_car_wcs* wcs_out, int proj_out, const int64_t shape_out[2],
+                            void* stream, pxl_generic_plan** plan) {
+    if (!plan) return fail(PXL_EINVAL, "generic_plan_create: null result");
+    *plan = nullptr;
+    GenericParams p;
+    int rc = generic_params("generic_plan_create", wcs_in, proj_in, shape_in, wcs_out, proj_out, shape_out, &p);
+    if (rc) return rc;
+    const int64_t gx = (p.nxo + PXL_TW - 1) / PXL_TW, gy = (p.nyo + PXL_TH - 1) / PXL_TH;
+    if (gy > 65535) return fail(PXL_EINVAL, "generic_plan_create: more than 65 535 tile rows (use the one-shot entry)");
+    const int64_t ntiles = gx * gy;
+    const size_t lat_bytes = (size_t)ntiles * (PXL_TNX * PXL_TNY) * sizeof(double2), flag_bytes = ((size_t)ntiles * 4 + 15) & ~(size_t)15;
+    pxl_generic_plan* pl = new (std::nothrow) pxl_generic_plan();
+    if (!pl) return fail(PXL_ENOMEM, "generic_plan_create: out of host memory");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipGetDevice(&pl->device);
+    if (e == hipSuccess) e = hipMalloc((void**)&pl->ws, lat_bytes + flag_bytes + 16);
+    if (e != hipSuccess) { (void)hipGetLastError(); delete pl; return fail(PXL_EHIP, "generic_plan_create: %s", hipGetErrorString(e)); }
+    pl->lat = (double2*)pl->ws; pl->flag = (int32_t*)(pl->ws + lat_bytes); pl->counter = (unsigned int*)(pl->ws + lat_bytes + flag_bytes);
+    pl->gx = gx; pl->gy = gy; pl->ntiles = ntiles;
+    p.exact_tiles = pl->counter; p.exact_tiles_next = nullptr;
+    pl->p = p;
+    unsigned int host_count = 0;
+    e = hipMemsetAsync(pl->counter, 0, 16, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_generic_lattice, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, p, gx, ntiles, pl->lat, pl->flag);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&host_count, pl->counter, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { (void)hipFree(pl->ws); delete pl; return fail(PXL_EHIP, "generic_plan_create: %s", hipGetErrorString(e)); }
+    pl->exact = host_count;
+    *plan = pl;
+    return PXL_OK;
+}
+
+int pxl_generic_plan_execute(const pxl_generic_plan* plan, int64_t ncomp, const double* src, double* dst, void* stream) {
+    if (!plan) return fail(PXL_EINVAL, "generic_plan_execute: null plan");
+    if (ncomp < 1 || ncomp > 0x7fffffff) return fail(PXL_EINVAL, "generic_plan_execute: component count must be positive");
+    if (!src || !dst) return fail(PXL_EINVAL, "generic_plan_execute: null src/dst");
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != plan->device) return fail(PXL_EINVAL, "generic_plan_execute: plan belongs to device %d, current device is %d", plan->device, dev);
+    GenericParams p = plan->p;
+    p.src = src; p.dst = dst; p.nc = (int32_t)ncomp;
+    hipStream_t st = (hipStream_t)stream;
+    launch_generic_pixels(p, plan->gx, plan->gy, plan->lat, plan->flag, st);
+    if (plan->exact > 0)       // known on the host since the plan was made: no launch at all for the usual patch
+        hipLaunchKernelGGL(k_reproject_generic_exact_tiles, dim3((unsigned)std::min<int64_t>(plan->ntiles, 256)), dim3(256), 0, st, p, (const int32_t*)plan->flag, plan->gx, plan->ntiles);
+    return check_launch("k_reproject_generic_tiled (plan)");
+}
+
+int pxl_generic_plan_tiles(const pxl_generic_plan* plan, int64_t* exact_tiles, int64_t* total_tiles) {
+    if (!plan || !exact_tiles || !total_tiles) return fail(PXL_EINVAL, "generic_plan_tiles: null argument");
+    *exact_tiles = plan->exact; *total_tiles = plan->ntiles;
+    return PXL_OK;
+}
+
+int pxl_generic_plan_destroy(pxl_generic_plan* plan) {
+    if (!plan) return PXL_OK;
+    hipError_t e = plan->ws ? hipFree(plan->ws) : hipSuccess;
+    delete plan;
+    if (e != hipSuccess) return fail(PXL_EHIP, "generic_plan_destroy: %s", hipGetErrorString(e));
+    return PXL_OK;
+}
+
+int pxl_reproject_generic_bilinear_f64(const pxl_car_wcs* wcs_in, int proj_in, const int64_t shape_in[3],
+                                       const double* src, const pxl_car_wcs* wcs_out, int proj_out,
+                                       const int64_t shape_out[2], double* dst, void* stream) {
+    GenericParams p;
+    int rcp = generic_params("reproject_generic", wcs_in, proj_in, shape_in, wcs_out, proj_out, shape_out, &p);
+    if (rcp) return rcp;
+    if (shape_in[2] < 1) return fail(PXL_EINVAL, "reproject_generic: shapes must be positive");
+    if (!src || !dst) return fail(PXL_EINVAL, "reproject_generic: null src/dst");
+    p.src = src; p.dst = dst; p.nc = (int32_t)shape_in[2];
     // PXL_GENERIC_EXACT=1: per-pixel evaluation of the coordinates (the definition; cross-check and fallback of the
     // tiled kernel, which interpolates them per 128 x 32 tile within PXL_TILED_TOL pixel)
     const int64_t gx = (p.nxo + PXL_TW - 1) / PXL_TW, gy = (p.nyo + PXL_TH - 1) / PXL_TH;
@@ -1170,12 +1263,7 @@ int pxl_reproject_generic_bilinear_f64(const pxl_car_wcs* wcs_in, int proj_in, c
     double2* lat = (double2*)ws;
     int32_t* flag = (int32_t*)(ws + lat_bytes);
     hipLaunchKernelGGL(k_generic_lattice, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, p, gx, ntiles, lat, flag);
-    // PXL_GENERIC_V=1: round 3's pixel kernel (one pixel per lane, 8-byte taps, ~99 VALU per pixel), kept for A/B; default: the lean
-    // round-4 form.  (Two more forms were built, measured slower and moved to tools/research/: two pixels per lane, the LDS ring.)
-    if (env_int("PXL_GENERIC_V", 3) == 1 || env_int("PXL_GENERIC_V1", 0))
-        hipLaunchKernelGGL(k_reproject_generic_tiled, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, (const double2*)lat, (const int32_t*)flag);
-    else
-        hipLaunchKernelGGL(k_reproject_generic_tiled3, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p, (const double2*)lat, (const int32_t*)flag);
+    launch_generic_pixels(p, gx, gy, (const double2*)lat, (const int32_t*)flag, st);
     hipLaunchKernelGGL(k_reproject_generic_exact_tiles, dim3((unsigned)std::min<int64_t>(ntiles, 256)), dim3(256), 0, st, p, (const int32_t*)flag, gx, ntiles);
     int rc = check_launch("k_reproject_generic_tiled");
     hipError_t fe = hipFreeAsync(ws, st);

@@ -372,7 +372,7 @@ def reproject(m: Enmap, shape_out, wcs_out, out: Enmap = None, plan: ReprojectPl
     Not in the reference; composes posmap(out) o sky2pix(in) o 2x2 gather + lerp."""
     nxo, nyo = int(shape_out[0]), int(shape_out[1])
     if isinstance(m.wcs, Gnomonic) or isinstance(wcs_out, Gnomonic):
-        return _reproject_generic(m, (nxo, nyo), wcs_out, out)
+        return _reproject_generic(m, (nxo, nyo), wcs_out, out, plan)
     if plan is None:
         plan = ReprojectPlan(m.shape, m.wcs, shape_out, wcs_out, device=m.device)
     if out is None:
@@ -387,17 +387,82 @@ def reproject(m: Enmap, shape_out, wcs_out, out: Enmap = None, plan: ReprojectPl
     return out
 
 
-def _reproject_generic(m: Enmap, shape_out, wcs_out, out=None) -> Enmap:
-    """CAR <-> Gnomonic (non-separable) bilinear reprojection: pxl_reproject_generic_bilinear_f64."""
+def _proj_code(w):
+    if not isinstance(w, (AbstractCARWCS, Gnomonic)):
+        raise TypeError("generic reprojection handles CAR and Gnomonic WCS only")
+    return 1 if isinstance(w, Gnomonic) else 0   # PXL_PROJ_TAN / PXL_PROJ_CAR
+
+
+class GenericReprojectPlan:
+    """Owns a pxl_generic_plan: the coordinate lattice of a CAR <-> Gnomonic reprojection (42 exact evaluations and 12 check
+    points per 128 x 32 output tile) and the list of tiles that are evaluated per pixel.  What ReprojectPlan's tables are to
+    the separable CAR -> CAR path: make it once per pair of geometries, execute it on as many maps as there are --
+    `pj.reproject(m, shape_out, wcs_out, out=out, plan=plan)`.  Same results as the one-shot call, bit for bit."""
+
+    def __init__(self, shape_in, wcs_in, shape_out, wcs_out, device="cuda"):
+        self.shape_in = (int(shape_in[0]), int(shape_in[1]))
+        self.shape_out = (int(shape_out[0]), int(shape_out[1]))
+        self.wcs_in, self.wcs_out = wcs_in, wcs_out
+        self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(_lib.load().pxl_generic_plan_create(
+                _wcs_ref(wcs_in), _proj_code(wcs_in), _shape2(self.shape_in),
+                _wcs_ref(wcs_out), _proj_code(wcs_out), _shape2(self.shape_out), s, C.byref(self._h)))
+
+    def tiles(self):
+        """(tiles evaluated per pixel, all tiles)"""
+        a, b = C.c_int64(), C.c_int64()
+        _lib.check(_lib.load().pxl_generic_plan_tiles(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def execute(self, src, dst):
+        src, dst = _dev_f64(src, "src"), _dev_f64(dst, "dst")
+        nx, ny = self.shape_in
+        if src.dim() not in (2, 3) or tuple(src.shape[-2:]) != (ny, nx):
+            raise ValueError("src has shape %s, plan expects (..., %d, %d)" % (tuple(src.shape), ny, nx))
+        nc = src.shape[0] if src.dim() == 3 else 1
+        if dst.numel() != nc * self.shape_out[0] * self.shape_out[1]:
+            raise ValueError("dst has %d elements, plan expects %d x %d x %d" % (dst.numel(), nc, self.shape_out[1], self.shape_out[0]))
+        if src.device != self.device or dst.device != self.device:
+            raise ValueError("plan lives on %s" % (self.device,))
+        if src.data_ptr() == dst.data_ptr():
+            raise ValueError("src and dst must not alias")
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().pxl_generic_plan_execute(self._h, nc, _ptr(src), _ptr(dst), _stream(dst)))
+        return dst
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.load().pxl_generic_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _reproject_generic(m: Enmap, shape_out, wcs_out, out=None, plan=None) -> Enmap:
+    """CAR <-> Gnomonic (non-separable) bilinear reprojection: pxl_reproject_generic_bilinear_f64, or a GenericReprojectPlan."""
     data = _dev_f64(m.data, "map data")
-    for w in (m.wcs, wcs_out):
-        if not isinstance(w, (AbstractCARWCS, Gnomonic)):
-            raise TypeError("generic reprojection handles CAR and Gnomonic WCS only")
+    code = _proj_code
+    code(m.wcs), code(wcs_out)
     nc = data.shape[0] if data.dim() == 3 else 1
     if out is None:
         oshape = (shape_out[1], shape_out[0]) if data.dim() == 2 else (nc, shape_out[1], shape_out[0])
         out = Enmap(torch.empty(oshape, dtype=torch.float64, device=data.device), wcs_out)
-    code = lambda w: 1 if isinstance(w, Gnomonic) else 0   # PXL_PROJ_TAN / PXL_PROJ_CAR
+    if plan is not None:
+        if not isinstance(plan, GenericReprojectPlan):
+            raise TypeError("a CAR <-> Gnomonic reprojection takes a GenericReprojectPlan")
+        if plan.shape_in != (int(m.shape[0]), int(m.shape[1])) or plan.shape_out != (int(shape_out[0]), int(shape_out[1])):
+            raise ValueError("plan was made for %s -> %s" % (plan.shape_in, plan.shape_out))
+        plan.execute(data, out.data)
+        return out
     with torch.cuda.device(data.device):
         _lib.check(_lib.load().pxl_reproject_generic_bilinear_f64(
             _wcs_ref(m.wcs), code(m.wcs), _lib.shape_arr((m.shape[0], m.shape[1], nc)), _ptr(data),

@@ -58,9 +58,9 @@ _JULIA_TO_C = {
     "Ref{CarWCS}": {"pxl_car_wcs*"},
     "Int64": {"int64_t"}, "UInt64": {"uint64_t"}, "Cint": {"int"}, "Cdouble": {"double"}, "Csize_t": {"size_t"},
     "Ptr{Cdouble}": {"double*"}, "Ptr{Cfloat}": {"float*"}, "Ptr{Int64}": {"int64_t*"},
-    "Ptr{Cvoid}": {"void*", "pxl_reproject_plan*", "pxl_mem_pair*"},
+    "Ptr{Cvoid}": {"void*", "pxl_reproject_plan*", "pxl_generic_plan*", "pxl_mem_pair*"},
     "Ref{MemPlacedInfo}": {"pxl_mem_placed_info*"},
-    "Ptr{Ptr{Cvoid}}": {"void**", "pxl_reproject_plan**"},
+    "Ptr{Ptr{Cvoid}}": {"void**", "pxl_reproject_plan**", "pxl_generic_plan**"},
     "Ptr{UInt8}": {"char*", "void*"},
     "Ptr{HaloXfer}": {"pxl_halo_xfer*"},
     "Cstring": {"char*"},

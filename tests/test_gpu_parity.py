@@ -672,6 +672,56 @@ def test_generic_reproject_car_tan(pj, O, dev, literals):
     assert bits_equal(gen, exp)
 
 
+def test_generic_reproject_plan_equals_one_shot(pj, O, dev):
+    """GenericReprojectPlan (pxl_generic_plan_*: the coordinate lattice and the per-pixel tile list kept between calls) gives the
+    bits of the one-shot entry -- same kernels, same lattice -- for one and several components, for CAR -> TAN, TAN -> CAR and
+    TAN -> TAN, on a patch that straddles the RA seam of a periodic source (tiles across the rewind jump are evaluated per pixel:
+    the plan must launch that kernel too) and on coarse pixels (every tile per pixel); it is reusable on other maps of the same
+    geometry, checks what it is given, and matches the oracle."""
+    rng = np.random.default_rng(5)
+    # a declination strip of the 0.5' full-sky map (full rings: periodic), as in the test above; the interpolant passes its check at
+    # 0.5' pixels and fails it everywhere at 40'
+    fshape, fwcs = pj.fullsky_geometry(2 * math.pi / 43200)
+    fshape, fwcs = pj.slice_geometry(fshape, fwcs, None, (10801 - 500, 10801 + 500))
+    seam = ((700, 500), pj.Gnomonic((0.5 / 60, 0.5 / 60), (350.5, 250.5), (179.9, 0.3)))
+    inner = ((520, 300), pj.Gnomonic((0.5 / 60, 0.5 / 60), (260.5, 150.5), (40.0, -1.0)))
+    coarse = ((300, 200), pj.Gnomonic((40.0 / 60, 40.0 / 60), (150.5, 100.5), (10.0, 3.0)))
+    xx = np.arange(fshape[0])[None, :]
+    yy = np.arange(fshape[1])[:, None]
+    smooth = np.stack([np.sin(0.01 * (c + 1) * xx) * np.cos(0.013 * yy) + 0.001 * c * xx for c in range(2)])
+    for (oshape, owcs), nc, want_exact in ((seam, 1, "some"), (inner, 2, "none"), (coarse, 2, "all")):
+        src = smooth[:nc]
+        m = pj.Enmap(to_dev(src if nc > 1 else src[0], dev), fwcs)
+        one = pj.reproject(m, oshape, owcs)
+        plan = pj.GenericReprojectPlan(fshape, fwcs, oshape, owcs, device=dev)
+        ex, tot = plan.tiles()
+        assert tot == -(-oshape[0] // 128) * -(-oshape[1] // 32)
+        assert {"some": 0 < ex < tot, "none": ex == 0, "all": ex == tot}[want_exact], (ex, tot)
+        out = pj.Enmap(torch.full_like(one.data, float("nan")), owcs)
+        got = pj.reproject(m, oshape, owcs, out=out, plan=plan)
+        assert got is out
+        assert bits_equal(out.data.cpu().numpy(), one.data.cpu().numpy()), want_exact
+        exp = O.reproject_generic(fwcs, 0, (fshape[0], fshape[1], nc), src, owcs, 1, oshape)
+        assert np.abs(out.data.cpu().numpy().reshape(nc, oshape[1], oshape[0]) - exp).max() < 1e-9
+        # the same plan on another map of the geometry, another component count
+        m2 = pj.Enmap(torch.randn((3, fshape[1], fshape[0]), dtype=torch.float64, device=dev), fwcs)
+        assert bits_equal(pj.reproject(m2, oshape, owcs, plan=plan).data.cpu().numpy(), pj.reproject(m2, oshape, owcs).data.cpu().numpy())
+        with pytest.raises(ValueError):
+            pj.reproject(m2, (oshape[0] + 1, oshape[1]), owcs, plan=plan)
+        with pytest.raises(ValueError):
+            plan.execute(m2.data[:, :-1, :].contiguous(), out.data)
+        plan.close()
+    # TAN -> CAR and TAN -> TAN
+    tshape, twcs = inner
+    tmap = pj.Enmap(to_dev(smooth[0][:tshape[1], :tshape[0]].copy(), dev), twcs)
+    cshape, cwcs = pj.geometry([[41 * DEG, 39 * DEG], [-2 * DEG, 0 * DEG]], 0.5 * ARCMIN)
+    for oshape, owcs in ((cshape, cwcs), ((200, 180), pj.Gnomonic((0.6 / 60, 0.6 / 60), (100.0, 90.0), (40.2, -1.1)))):
+        plan = pj.GenericReprojectPlan(tshape, twcs, oshape, owcs, device=dev)
+        assert bits_equal(pj.reproject(tmap, oshape, owcs, plan=plan).data.cpu().numpy(), pj.reproject(tmap, oshape, owcs).data.cpu().numpy())
+    with pytest.raises(TypeError):
+        pj.reproject(tmap, cshape, cwcs, plan=pj.ReprojectPlan(fshape, fwcs, fshape, fwcs, device=dev))
+
+
 def test_rewind_and_unwind_entries(pj, O, dev):
     """Standalone rewind! / unwind! (enmap_ops.jl:15-32) with the periods and reference angles the reference
     itself uses: 2*pi about 0 for angles, the pixel period about the map centre for sky2pix."""
