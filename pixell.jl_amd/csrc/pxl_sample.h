@@ -360,7 +360,9 @@ __global__ __launch_bounds__(256) void k_reproject_generic_tiled3(GenericParams 
                     // non-temporal: the output is never read back here, and kept out of the caches it leaves them to the taps that
                     // neighbouring rows and tiles share (mosaic of 16 patches, plans reused: 1.10 -> 1.04-1.05 ms; rows in groups of 2 or
                     // 8, a rolled row loop: no better; tiles handed out so that each XCD covers a contiguous eighth of the patch:
-                    // 1.075 against 1.056 ms)
+                    // 1.075 against 1.056 ms; right taps taken from the neighbouring lane by DPP where it starts one cell further, own
+                    // 8-byte loads elsewhere -- half the bytes through the texture addresser: 1.24-1.57 against 1.06 ms, the masked
+                    // second round of loads costs more than the pair loads' overlap)
                     __builtin_nontemporal_store((1 - fy[g]) * top + fy[g] * bot, &p.dst[(int64_t)c * total + (tj0 + ry + PXL_TROWS * (q0 + g)) * p.nxo + i]);
                 }
             }
