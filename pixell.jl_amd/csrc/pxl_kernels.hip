@@ -76,6 +76,10 @@ static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
 }
+static int64_t env_int64(const char* name, int64_t dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? (int64_t)atoll(v) : dflt;
+}
 
 #include "pxl_elementwise.h"
 #include "pxl_unwrap.h"
@@ -249,7 +253,12 @@ static int unwind_onepass(const SRC& src, typename SRC::raw_t* out, int64_t n, U
     if (w.nlinks > 0x7fffffffLL) return fail(PXL_EINVAL, "unwind: batch too long");
     hipError_t e = hipMemsetAsync(w.links, 0, (size_t)w.nlinks * sizeof(UwLink) + 16, st);
     if (e != hipSuccess) return fail(PXL_EHIP, "unwind: hipMemsetAsync: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL((k_unwind_onepass<SRC>), dim3((unsigned)w.nlinks), dim3(64 * PXL_UW1_WAVES), 0, st, src, out, n, w.links, w.ticket, w.flag + 2);
+    if (n >= env_int64("PXL_UNWIND_BIG_FROM", PXL_UW1_BIG_FROM)) {
+        const int64_t nwg = (n + PXL_UW1_BIG_CHUNK - 1) / PXL_UW1_BIG_CHUNK;          // <= nlinks (sized for the smaller chunk)
+        hipLaunchKernelGGL((k_unwind_onepass<SRC, PXL_UW1_BIG_U, PXL_UW1_BIG_UL>), dim3((unsigned)nwg), dim3(64 * PXL_UW1_WAVES), 0, st, src, out, n, w.links, w.ticket, w.flag + 2);
+    } else {
+        hipLaunchKernelGGL((k_unwind_onepass<SRC, PXL_UW1_U, PXL_UW1_UL>), dim3((unsigned)w.nlinks), dim3(64 * PXL_UW1_WAVES), 0, st, src, out, n, w.links, w.ticket, w.flag + 2);
+    }
     return check_launch("k_unwind_onepass");
 }
 

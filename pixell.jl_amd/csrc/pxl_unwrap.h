@@ -482,6 +482,15 @@ __device__ inline unsigned long long uw_peek(const unsigned long long* p) {
 #ifndef PXL_UW1_CHUNK
 #define PXL_UW1_CHUNK (64LL * (PXL_UW1_U + PXL_UW1_UL) * PXL_UW1_WAVES)       // points per workgroup and link
 #endif
+// Long batches take chunks of 13 312 points, ONE workgroup per CU (4 groups per wave in registers, 9 in LDS: 153 KB of the CU's
+// 160): 0.71-0.73 ms per 1e8 points where the 7 168-point chunks take 0.74-0.78 (tools/research/r04_36.sh); below
+// PXL_UW1_BIG_FROM points the smaller chunks are as fast or faster (2e7 points: 0.186 against 0.192 ms; 8e6: 0.102 / 0.107).
+#define PXL_UW1_BIG_U 4
+#define PXL_UW1_BIG_UL 9
+#define PXL_UW1_BIG_CHUNK (64LL * (PXL_UW1_BIG_U + PXL_UW1_BIG_UL) * PXL_UW1_WAVES)
+#ifndef PXL_UW1_BIG_FROM
+#define PXL_UW1_BIG_FROM 50000000LL
+#endif
 #ifndef PXL_UW1_WIN
 #define PXL_UW1_WIN 1          // 64-link windows wave 0 reads per look-back round.  More windows per round are slower whether or not the
 #endif                         // registers allow two workgroups per CU (more polling traffic): 1 / 2 / 3 windows 0.84 / 0.89-0.91 / 0.92-0.95 ms at
@@ -507,10 +516,10 @@ __device__ inline UwGather uw_gather(const int (*wsum)[NW], const int* wnan, int
     return g;
 }
 
-template <class SRC>
+template <class SRC, int U, int UL>
 __global__ __launch_bounds__(64 * PXL_UW1_WAVES) void k_unwind_onepass(SRC src, typename SRC::raw_t* out, int64_t n, UwLink* __restrict__ links,
                                                                        unsigned int* __restrict__ ticket, int32_t* __restrict__ flag) {
-    constexpr int U = PXL_UW1_U, UL = PXL_UW1_UL, NROW = SRC::NROW, NW = PXL_UW1_WAVES;
+    constexpr int NROW = SRC::NROW, NW = PXL_UW1_WAVES;
     __shared__ unsigned int id_s;
     __shared__ int wsum_s[2][NW], wnan_s[NW];
     __shared__ int excl_s[2];
