@@ -76,10 +76,6 @@ static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
 }
-static int64_t env_int64(const char* name, int64_t dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? (int64_t)atoll(v) : dflt;
-}
 
 #include "pxl_elementwise.h"
 #include "pxl_unwrap.h"
@@ -253,12 +249,8 @@ static int unwind_onepass(const SRC& src, typename SRC::raw_t* out, int64_t n, U
     if (w.nlinks > 0x7fffffffLL) return fail(PXL_EINVAL, "unwind: batch too long");
     hipError_t e = hipMemsetAsync(w.links, 0, (size_t)w.nlinks * sizeof(UwLink) + 16, st);
     if (e != hipSuccess) return fail(PXL_EHIP, "unwind: hipMemsetAsync: %s", hipGetErrorString(e));
-    if (n >= env_int64("PXL_UNWIND_BIG_FROM", PXL_UW1_BIG_FROM)) {
-        const int64_t nwg = (n + PXL_UW1_BIG_CHUNK - 1) / PXL_UW1_BIG_CHUNK;          // <= nlinks (sized for the smaller chunk)
-        hipLaunchKernelGGL((k_unwind_onepass<SRC, PXL_UW1_BIG_U, PXL_UW1_BIG_UL>), dim3((unsigned)nwg), dim3(64 * PXL_UW1_WAVES), 0, st, src, out, n, w.links, w.ticket, w.flag + 2);
-    } else {
-        hipLaunchKernelGGL((k_unwind_onepass<SRC, PXL_UW1_U, PXL_UW1_UL>), dim3((unsigned)w.nlinks), dim3(64 * PXL_UW1_WAVES), 0, st, src, out, n, w.links, w.ticket, w.flag + 2);
-    }
+    const int64_t nwg = (n + PXL_UW1_CHUNK - 1) / PXL_UW1_CHUNK;
+    hipLaunchKernelGGL((k_unwind_onepass<SRC, PXL_UW1_U, PXL_UW1_UL>), dim3((unsigned)nwg), dim3(64 * PXL_UW1_WAVES), 0, st, src, out, n, w.links, w.ticket, w.flag + 2);
     return check_launch("k_unwind_onepass");
 }
 
@@ -392,7 +384,7 @@ int pxl_pix2sky_car_f64(const pxl_car_wcs* wcs, int64_t n, const double* pix, do
     if (rc) return rc;
     UwSrcPix2 src{c, (const double2*)pix, PXL_TWOPI_D, 0.0, 1.0 / PXL_TWOPI_D};
     // out of place: one pass (input read once, the exact rewind evaluated once); in place: sums -> scan -> verify -> store
-    if (pa != sa && env_int("PXL_UNWIND_ONEPASS", 1)) rc = unwind_onepass(src, (double2*)sky, n, w, st);
+    if (pa != sa && n < PXL_UW_ONEPASS_MAX && env_int("PXL_UNWIND_ONEPASS", 1)) rc = unwind_onepass(src, (double2*)sky, n, w, st);
     else rc = unwind_fused(src, (double2*)sky, n, pa == sa, w, st);
     if (rc == PXL_OK) {
         const int32_t* failed = w.flag + 2;

@@ -455,13 +455,76 @@ __global__ __launch_bounds__(64) void k_unwind_apply(SRC src, typename SRC::raw_
 #ifndef PXL_UW1_UL
 #define PXL_UW1_UL 4           // ... and kept in LDS (first in the wave's run of points)
 #endif
-struct UwLink { unsigned long long agg, pre0, pre1, pad; };          // 32 bytes per chunk
+// A link is ONE naturally aligned 8-byte word, written whole by one agent-scope relaxed store and read whole by one such load
+// (data and "ready" arrive together, no fence): bits 0-1 status (0 nothing yet, 1 this chunk's AGGREGATE, 2 the inclusive PREFIX up
+// to and including this chunk -- the prefix overwrites the aggregate, a reader can use either), bits 2-3 "a NaN in row 0 / 1" (of the
+// chunk / up to the chunk), bits 4-33 and 34-63 the two rows' counts as 30-bit two's complement (|count| <= points so far: batches
+// of 2^29 points and more take the two-pass form).  (Round 4's first form kept aggregate and the two prefixes in three words of a
+// 32-byte link: three loads per link and poll.)
+#ifndef PXL_UW_LINK_WORDS
+#define PXL_UW_LINK_WORDS 8            // link stride in 8-byte words
+#endif
+struct UwLink { unsigned long long w; unsigned long long pad[PXL_UW_LINK_WORDS - 1]; };
+#define PXL_UW_ONEPASS_MAX (1LL << 29)
 
-__device__ inline void uw_publish(unsigned long long* p, unsigned int payload, unsigned int tag) {
-    __hip_atomic_store(p, ((unsigned long long)payload << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ inline unsigned long long uw_pack(int v0, int v1, unsigned int nan2, unsigned int status) {
+    return (unsigned long long)(status & 3u) | ((unsigned long long)(nan2 & 3u) << 2) |
+           ((unsigned long long)((unsigned int)v0 & 0x3fffffffu) << 4) | ((unsigned long long)((unsigned int)v1 & 0x3fffffffu) << 34);
 }
-__device__ inline unsigned long long uw_peek(const unsigned long long* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ inline void uw_publish(UwLink* p, int v0, int v1, unsigned int nan2, unsigned int status) {
+    __hip_atomic_store(&p->w, uw_pack(v0, v1, nan2, status), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline unsigned long long uw_peek(const UwLink* p) {
+    return __hip_atomic_load(&p->w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline int uw_field0(unsigned long long w) { return ((int)((unsigned int)(w >> 4) << 2)) >> 2; }
+__device__ inline int uw_field1(unsigned long long w) { return ((int)((unsigned int)(w >> 34) << 2)) >> 2; }
+
+// The exclusive carry of link `id` (one wave): lane l reads link top - l of a 64-link window (WIN windows per round trip); up to the
+// nearest link that holds a prefix the aggregates are added, a link with nothing yet means poll the round again, a round without a
+// prefix moves WIN windows further back.  Links before the first one count as a prefix of zero.  Polls are bounded: a wave that makes
+// no progress 2^22 times gives up (the caller raises the failure flag and publishes what it has, so every wave ends).
+template <int WIN>
+__device__ inline void uw_lookback(const UwLink* links, int64_t id, int lane, int* E, unsigned int* nan_before, bool* gave_up) {
+    E[0] = E[1] = 0; *nan_before = 0; *gave_up = false;
+    if (id <= 0) return;
+    int64_t top = id - 1;
+    unsigned int polls = 0;
+    for (;;) {
+        unsigned long long w[WIN];
+#pragma unroll
+        for (int q = 0; q < WIN; ++q) {
+            const int64_t j = top - 64 * q - lane;
+            w[q] = j >= 0 ? uw_peek(&links[j]) : 2ull;              // status 2, counts 0
+        }
+        int e0 = 0, e1 = 0;
+        unsigned int en = 0;
+        int state = 0;                   // 0: no prefix met yet; 1: done; 2: a link before the first prefix holds nothing yet
+#pragma unroll
+        for (int q = 0; q < WIN; ++q) {
+            const unsigned int st = (unsigned int)w[q] & 3u;
+            const unsigned long long pmask = __ballot(st == 2u), amask = __ballot(st != 0u);
+            const int first = pmask ? __builtin_ctzll(pmask) : 64;          // nearest link of this window with a prefix
+            const unsigned long long need = first >= 64 ? ~0ull : ((1ull << first) - 1ull);
+            const bool mine = lane <= first;                                 // aggregates before it and the prefix itself
+            const int s0 = uw_wave_total(mine ? uw_field0(w[q]) : 0), s1 = uw_wave_total(mine ? uw_field1(w[q]) : 0);
+            const unsigned int nb = mine ? ((unsigned int)w[q] >> 2) & 3u : 0u;
+            const unsigned int nbw = (__ballot(nb & 1u) != 0ull ? 1u : 0u) | (__ballot(nb & 2u) != 0ull ? 2u : 0u);
+            if (state == 0) {
+                if ((amask & need) != need) state = 2;
+                else { e0 += s0; e1 += s1; en |= nbw; if (first < 64) state = 1; }
+            }
+        }
+        if (state == 2) {
+            if (++polls > (1u << 22)) { *gave_up = true; return; }
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        E[0] += e0; E[1] += e1; *nan_before |= en;
+        if (state == 1) return;
+        top -= 64 * WIN;
+        polls = 0;
+    }
 }
 
 // PXL_UW1_WAVES waves of a workgroup share one chunk (64 * (PXL_UW1_U + PXL_UW1_UL) points each, back to back) and ONE link: their sums
@@ -482,15 +545,8 @@ __device__ inline unsigned long long uw_peek(const unsigned long long* p) {
 #ifndef PXL_UW1_CHUNK
 #define PXL_UW1_CHUNK (64LL * (PXL_UW1_U + PXL_UW1_UL) * PXL_UW1_WAVES)       // points per workgroup and link
 #endif
-// Long batches take chunks of 13 312 points, ONE workgroup per CU (4 groups per wave in registers, 9 in LDS: 153 KB of the CU's
-// 160): 0.71-0.73 ms per 1e8 points where the 7 168-point chunks take 0.74-0.78 (tools/research/r04_36.sh); below
-// PXL_UW1_BIG_FROM points the smaller chunks are as fast or faster (2e7 points: 0.186 against 0.192 ms; 8e6: 0.102 / 0.107).
-#define PXL_UW1_BIG_U 4
-#define PXL_UW1_BIG_UL 9
-#define PXL_UW1_BIG_CHUNK (64LL * (PXL_UW1_BIG_U + PXL_UW1_BIG_UL) * PXL_UW1_WAVES)
-#ifndef PXL_UW1_BIG_FROM
-#define PXL_UW1_BIG_FROM 50000000LL
-#endif
+// (Chunks of 13 312 points with ONE workgroup per CU -- 4 groups per wave in registers, 9 in LDS -- were 3-4 % faster than these while a
+// link was three words; with single-word links the two-workgroup form is the faster one: 0.70-0.71 against 0.71-0.74 ms.)
 #ifndef PXL_UW1_WIN
 #define PXL_UW1_WIN 1          // 64-link windows wave 0 reads per look-back round.  More windows per round are slower whether or not the
 #endif                         // registers allow two workgroups per CU (more polling traffic): 1 / 2 / 3 windows 0.84 / 0.89-0.91 / 0.92-0.95 ms at
@@ -607,72 +663,16 @@ __global__ __launch_bounds__(64 * PXL_UW1_WAVES) void k_unwind_onepass(SRC src, 
         const UwGather gt = uw_gather<NW>(wsum_s, wnan_s, lane, 0);
         const int T[2] = {gt.tot[0], gt.tot[1]};
         const unsigned int nan_here = gt.nan_all;
-        // 2. the aggregate: |T| <= 64 U NW (at most 15 360 for U = 15) fits 15 bits with its offset; two NaN bits on top
-        if (lane == 0) uw_publish(&links[id].agg, (unsigned)(T[0] + 16384) | ((unsigned)(T[1] + 16384) << 15) | (nan_here << 30), 1u);
+        // 2. the aggregate
+        if (lane == 0) uw_publish(&links[id], T[0], T[1], nan_here, 1u);
         // 3. look-back
-        int E[2] = {0, 0};
-        unsigned int nan_before = 0;
-        bool gave_up = false;
-        if (id > 0) {
-            // PXL_UW1_WIN windows of 64 links per round (1: more windows per round were measured slower, see the define)
-            int64_t top = id - 1;
-            unsigned int polls = 0;
-            for (;;) {
-                unsigned long long a[PXL_UW1_WIN], p0[PXL_UW1_WIN], p1[PXL_UW1_WIN];
-#pragma unroll
-                for (int wdw = 0; wdw < PXL_UW1_WIN; ++wdw) {
-                    const int64_t j = top - 64 * wdw - lane;
-                    a[wdw] = 0; p0[wdw] = 0; p1[wdw] = 0;
-                    if (j >= 0) {
-                        p0[wdw] = uw_peek(&links[j].pre0);
-                        p1[wdw] = NROW == 2 ? uw_peek(&links[j].pre1) : p0[wdw];
-                        a[wdw] = uw_peek(&links[j].agg);
-                    }
-                }
-                int e0 = 0, e1 = 0;
-                unsigned int en = 0;
-                int state = 0;                   // 0: no prefix met yet; 1: done; 2: an aggregate is missing before the first prefix
-#pragma unroll
-                for (int wdw = 0; wdw < PXL_UW1_WIN; ++wdw) {
-                    const int64_t j = top - 64 * wdw - lane;
-                    // chunks before the first one: an inclusive prefix of zero
-                    const bool hasP = j < 0 || (((unsigned)p0[wdw] & 1u) && ((unsigned)p1[wdw] & 1u));
-                    const bool hasA = j < 0 || ((unsigned)a[wdw] & 1u);
-                    const unsigned long long pmask = __ballot(hasP), amask = __ballot(hasA);
-                    const int first = pmask ? __builtin_ctzll(pmask) : 64;          // nearest link of this window with a prefix
-                    const unsigned long long need = first >= 64 ? ~0ull : ((1ull << first) - 1ull);
-                    int c0 = 0, c1 = 0;
-                    unsigned int nb = 0;
-                    if (j >= 0 && lane < first) {
-                        const unsigned int pa = (unsigned)(a[wdw] >> 32);
-                        c0 = (int)(pa & 0x7fffu) - 16384; c1 = (int)((pa >> 15) & 0x7fffu) - 16384; nb = pa >> 30;
-                    } else if (j >= 0 && lane == first) {
-                        c0 = (int)(unsigned)(p0[wdw] >> 32); c1 = (int)(unsigned)(p1[wdw] >> 32);
-                        nb = (((unsigned)p0[wdw] >> 1) & 1u) | ((((unsigned)p1[wdw] >> 1) & 1u) << 1);
-                    }
-                    const int s0 = uw_wave_total(c0), s1 = NROW == 2 ? uw_wave_total(c1) : 0;
-                    const unsigned int nbw = (__ballot(nb & 1u) != 0ull ? 1u : 0u) | (__ballot(nb & 2u) != 0ull ? 2u : 0u);
-                    if (state == 0) {
-                        if ((amask & need) != need) state = 2;
-                        else { e0 += s0; e1 += s1; en |= nbw; if (first < 64) state = 1; }
-                    }
-                }
-                if (state == 2) {                                                // an aggregate in between is not there yet
-                    if (++polls > (1u << 22)) { gave_up = true; break; }
-                    __builtin_amdgcn_s_sleep(2);
-                    continue;
-                }
-                E[0] += e0; E[1] += e1; nan_before |= en;
-                if (state == 1) break;
-                top -= 64 * PXL_UW1_WIN;
-                polls = 0;
-            }
-        }
-        // 4. the inclusive prefix (tag bit 1: a NaN in this row up to and including this chunk)
+        int E[2];
+        unsigned int nan_before;
+        bool gave_up;
+        uw_lookback<PXL_UW1_WIN>(links, id, lane, E, &nan_before, &gave_up);
+        // 4. the inclusive prefix replaces the aggregate (NaN bits: in this row up to and including this chunk)
         if (lane == 0) {
-            const unsigned int nn = nan_before | nan_here;
-            uw_publish(&links[id].pre0, (unsigned)(E[0] + T[0]), 1u | ((nn & 1u) << 1));
-            if (NROW == 2) uw_publish(&links[id].pre1, (unsigned)(E[1] + T[1]), 1u | (((nn >> 1) & 1u) << 1));
+            uw_publish(&links[id], E[0] + T[0], E[1] + T[1], nan_before | nan_here, 2u);
             excl_s[0] = E[0]; excl_s[1] = E[1]; nanb_s = nan_before; gaveup_s = gave_up ? 1u : 0u;
         }
     }

@@ -536,32 +536,20 @@ def test_unwind_one_pass_equals_two_pass(pj, O, dev):
     w3 = walk.copy()
     w3[1_500_000:, 0] = w3[1_499_999, 0] + math.pi * np.arange(1, n - 1_500_000 + 1)      # exact half-period steps from there on
     cases["ties"] = w3
-    import os
     for name, a in cases.items():
         exp = O.pix2sky(g[1], a, O.WRAP_UNWIND)
         d = to_dev(a, dev)
         one = pj.pix2sky_(g, d, torch.empty_like(d), safe=True).cpu().numpy()        # out of place: one pass, 7 168-point chunks
-        os.environ["PXL_UNWIND_BIG_FROM"] = "1"                                      # ... and the long-batch form: 13 312-point chunks
-        try:
-            big = pj.pix2sky_(g, d, torch.empty_like(d), safe=True).cpu().numpy()
-        finally:
-            del os.environ["PXL_UNWIND_BIG_FROM"]
         two = pj.pix2sky_(g, d, d, safe=True).cpu().numpy()                          # in place: two passes
         assert _same_bits_or_nan(one, exp), name
-        assert _same_bits_or_nan(big, exp), name
         assert _same_bits_or_nan(two, exp), name
-    # a longer batch through the long-batch form, on coordinates inside the interval (the wave vote) and wandering ones mixed
-    os.environ["PXL_UNWIND_BIG_FROM"] = "8000000"
+    # a longer batch (1 256 chunks), on coordinates inside the interval (the wave vote) and wandering ones mixed
     n = 9_000_011
     rng = np.random.default_rng(9)
     a = rng.uniform(-3.0, 3.0, (n, 2))
     a[n // 3: n // 2] += np.cumsum(rng.normal(0.0, 2.0, (n // 2 - n // 3, 2)), axis=0)
     d = to_dev(a, dev)
-    try:
-        got = pj.pix2sky_(g, d, torch.empty_like(d), safe=True).cpu().numpy()
-    finally:
-        del os.environ["PXL_UNWIND_BIG_FROM"]
-    assert bits_equal(got, O.pix2sky(g[1], a, O.WRAP_UNWIND))
+    assert bits_equal(pj.pix2sky_(g, d, torch.empty_like(d), safe=True).cpu().numpy(), O.pix2sky(g[1], a, O.WRAP_UNWIND))
 
 
 def test_unwind_in_range_vote_bit_exact(pj, O, dev):
