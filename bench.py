@@ -22,14 +22,15 @@ Workloads (BASELINE.json configs; natural Clenshaw-Curtis shapes, ny = nx/2 + 1)
     cfg2: (4096, 2049) -> (8192, 4097) (Infinity-Cache resident; informational).
     cfg5: 1e9 scattered (ra, dec) points sampled from a (43200, 21601) map replicated per GPU.
 
-Where the maps live (round 4): the headline uses the library's PLAIN pair allocation -- DecStripReprojector.alloc_pair, one
-allocation with the destination above the source, nothing probed, no head-room -- as VERDICT r03 item 2 prescribes when the
-class-aware default allocator (pj.empty_map, what pj.reproject allocates its output with) is not within 2 % of the
-144-GiB-head-room placement on every config (it is not: cfg3 0.69-0.795 against 0.79-0.81, and on cfg4's 20.9 GiB map a search
-measured slower than no search).  --api-default = source torch.empty + destination pj.empty_map, --placed = pj.place_pair (one
-allocation with 144 GiB of head-room: the best placement, rounds 1-3's headline policy), --two-allocations = two torch.empty; the
-default run reports three policies for every reprojection config (configs.*.api_default / .class_aware_placement /
-.plain_first_placement).
+Where the maps live (round 4): the headline's maps come from DecStripReprojector.alloc_maps() -- the library's default for a resident
+source / destination pair (placement.place_pair_shifted): ONE allocation of exactly the pair's size whose destination lies across
+a boundary between two of the HBM's memory classes; a scout allocation finds the boundaries with the library's store probe, a
+ballast shifts the pair onto one, both go back to the driver before the call returns.  Nothing is kept beyond the two maps, and
+nothing about this workload is timed.  (the 144-GiB-head-room placement is no longer the headline's; the plain
+pair -- alloc_pair, --arena -- is a lottery between processes: 0.70-0.79 of 8 TB/s, profiles/r04_headline_policy.txt.)
+--arena = alloc_pair (plain), --api-default = source torch.empty + destination pj.empty_map, --placed = pj.place_pair (144 GiB of
+head-room: the best placement, rounds 1-3's headline policy), --two-allocations = two torch.empty; the default run reports three
+policies for every reprojection config (configs.*.api_default / .class_aware_placement / .plain_first_placement).
 
 The default run (N = 1, workload cfg4) appends, after the headline and outside its timed region, a "configs" block
 with the other BASELINE configs measured in the same process (cfg2, cfg3, cfg3s, cfg5 at 1e9 points: ms per step,
@@ -245,6 +246,17 @@ def place_buffers(sh, candidates, dev, keep="first", arena=False):
                 pinfo = {"placement": "place_pair FAILED (%s): plain allocation, destination above the source" % type(e).__name__,
                          "allocation_GiB": None, "classes": None, "class_runs_label_from_to_GiB": None, "probe_us_same_class": None,
                          "probe_us_different_classes": None, "src_offset_GiB": None, "dst_offset_GiB": None, "source": None}
+        elif arena == "maps":   # DecStripReprojector.alloc_maps(): the library's default policy for a RESIDENT pair -- one allocation of exactly
+            # the pair's size, its destination shifted onto a class boundary by a ballast that is returned (placement.place_pair_shifted)
+            try:
+                src, dst, minfo = sh.alloc_maps()
+                holds.append(minfo.pop("arena", None))
+            except Exception as e:                   # noqa: BLE001 -- never lose a run to the placement
+                print("bench.py: alloc_maps failed (%s: %s); plain pair instead" % (type(e).__name__, str(e)[:200]), file=sys.stderr, flush=True)
+                torch.cuda.empty_cache()
+                src, dst, hold = sh.alloc_pair()
+                holds.append(hold)
+                minfo = {"placement": "alloc_maps FAILED (%s): plain pair" % type(e).__name__}
         elif arena == "api":    # what a caller of the drop-in API gets: the source in a plain allocation, the output allocated by the
             # library's default policy (placement.empty_map: two memory classes when a candidate turns up, no head-room kept)
             src = sh.alloc_src()
@@ -271,7 +283,7 @@ def place_buffers(sh, candidates, dev, keep="first", arena=False):
         if best is None or (keep == "best" and t < best[2]):
             best = (src, dst, t)
         del src, dst
-        if arena not in ("placed", "api"):
+        if arena not in ("placed", "api", "maps"):
             holds.clear()
         if k + 1 < candidates:
             # return the losing blocks to the driver and perturb the heap so the next try lands elsewhere
@@ -284,6 +296,9 @@ def place_buffers(sh, candidates, dev, keep="first", arena=False):
     alloc_desc = ("one allocation, destination above the source (DecStripReprojector.alloc_pair: fixed policy, nothing probed)" if arena else "two allocations")
     if arena == "placed":
         alloc_desc = {"policy": "pj.place_pair: one allocation with head-room, memory classes mapped with pxl_mem_probe_pair, destination across a class boundary", **pinfo}
+    if arena == "maps":
+        alloc_desc = {"policy": "DecStripReprojector.alloc_maps(): the library's default for a resident pair -- ONE allocation of exactly the pair's size, the "
+                                "destination put across a class boundary by a scout allocation and a ballast that are both returned (placement.place_pair_shifted)", **minfo}
     if arena == "api":
         alloc_desc = {"policy": "the library's default (what pj.reproject / DecStripReprojector.alloc_maps / the Julia HIPArray constructor allocate with): source "
                                 "torch.empty, destination pj.empty_map -- class-aware, no head-room kept", **ainfo}
@@ -362,11 +377,14 @@ def main():
                     help="buffer placements probed at setup (default 1: just the first allocation, which is what the "
                          "headline always reports unless --keep-placement best)")
     ap.add_argument("--api-default", dest="arena", action="store_const", const="api",
-                    default={"1": True, "0": False, "placed": "placed", "api": "api"}.get(os.environ.get("PXL_BENCH_ARENA", "1"), True),
+                    default={"1": True, "0": False, "placed": "placed", "api": "api", "maps": "maps"}.get(os.environ.get("PXL_BENCH_ARENA", "maps"), "maps"),
                     help="the maps as a caller of the drop-in API gets them: the source in a plain torch allocation, the "
                          "destination from the library's default allocation policy (pj.empty_map: a map of 3 GiB or more is looked for across a "
                          "boundary between two memory classes, rejected candidates are held only during the search, nothing but the map stays "
                          "allocated).  The default run reports the 144-GiB-head-room placement (--placed) and the plain one beside it")
+    ap.add_argument("--maps", dest="arena", action="store_const", const="maps",
+                    help="(the default) the maps from DecStripReprojector.alloc_maps(): one allocation of exactly the pair's size, destination across a class "
+                         "boundary, nothing else kept (placement.place_pair_shifted)")
     ap.add_argument("--placed", dest="arena", action="store_const", const="placed",
                     help="class-aware placement of the maps with head-room, pj.place_pair: ONE allocation with 144 GiB of head-room, its three "
                          "memory classes mapped with the library's store probe (pxl_mem_probe_pair, ~100 probes of 0.3 ms), the destination "
@@ -376,8 +394,8 @@ def main():
                          "candidates are compared.  With N > 1 every rank places its own strip pair.  The default run also reports the "
                          "plain first placement of the same workload (configs.*.plain_first_placement)")
     ap.add_argument("--arena", dest="arena", action="store_true",
-                    help="(the default) plain allocation, nothing probed: source and destination carved out of ONE allocation, destination above the "
-                         "source (DecStripReprojector.alloc_pair; the default of round 2 and again since round 4 -- VERDICT r03 item 2: fast for the 45 GB pair in 20 of 24 processes "
+                    help="plain allocation, nothing probed: source and destination carved out of ONE allocation, destination above the "
+                         "source (DecStripReprojector.alloc_pair; the default of round 2: fast for the 45 GB pair in 20 of 24 processes "
                          "because the driver's block boundary at 32 GiB falls into the destination, slow otherwise)")
     ap.add_argument("--two-allocations", dest="arena", action="store_false",
                     help="allocate the source and the destination separately (round 1's and early round 2's default)")
@@ -401,7 +419,7 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
-    if os.environ.get("PXL_BENCH_SHARE_GPU") and args.arena in ("placed", "api"):
+    if os.environ.get("PXL_BENCH_SHARE_GPU") and args.arena in ("placed", "api", "maps"):
         # rehearsal: several ranks on ONE device.  The class-aware policies hold ballast / head-room while they look for a class
         # boundary, which ranks sharing a device would fight over; a rehearsal checks the flow, not the rate: plain allocations
         args.arena = True
@@ -526,9 +544,9 @@ def bench_reproject(args, rank, world, dev):
     nx, ny, nc = shape_in
     nxo, nyo = shape_out
     sh = pj.DecStripReprojector(shape_in, wcs_in, shape_out, wcs_out, rank, world, dev)
-    if args.arena in ("placed", "api") and args.placements > 1:
+    if args.arena in ("placed", "api", "maps") and args.placements > 1:
         print("bench.py: --placements %d is ignored with the %s allocation policy (one fixed rule, first and only allocation)" % (args.placements, args.arena), file=sys.stderr, flush=True)
-    src, dst, placement = place_buffers(sh, 1 if args.arena in ("placed", "api") else args.placements, dev, args.keep_placement, arena=args.arena)
+    src, dst, placement = place_buffers(sh, 1 if args.arena in ("placed", "api", "maps") else args.placements, dev, args.keep_placement, arena=args.arena)
     torch.cuda.synchronize(dev)
     # ---- choose the halo transport (N > 1).  Candidates in order: "native" = the library's own sharded step (RCCL
     # send/recv issued from C straight out of / into the resident buffer), "torch" = torch.distributed
@@ -929,7 +947,7 @@ def side_measurements(args, dev, result):
     result["configs"] = cfgs
     # the headline's workload under the two other allocation policies, at the top of the roofline block
     if "cfg4" in cfgs and "roofline" in result:
-        result["roofline"]["headline_allocation_policy"] = {True: "plain (alloc_pair)", False: "two plain allocations", "placed": "pj.place_pair (144 GiB head-room)",
+        result["roofline"]["headline_allocation_policy"] = {True: "plain (alloc_pair)", False: "two plain allocations", "placed": "pj.place_pair (144 GiB head-room)", "maps": "DecStripReprojector.alloc_maps (exact pair, destination across a class boundary)",
                                                             "api": "the library's default (pj.empty_map: class-aware, no head-room)"}.get(args.arena, str(args.arena))
         result["roofline"]["frac_other_policies"] = {"class_aware_placement_144GiB_headroom": cfgs["cfg4"]["class_aware_placement"]["frac"],
                                                      "plain_first_placement": cfgs["cfg4"]["plain_first_placement"]["frac"],

@@ -17,7 +17,7 @@ from .ops import (GenericReprojectPlan, ReprojectPlan, SamplePairs, fill_random_
                   pixareamap, pixareamap_, posmap, reproject, rewind_, sample_bilinear, sky2pix, sky2pix_,
                   sky2pix_broadcast, unwind_)
 from .sharding import DecStripLayout, DecStripReprojector, strip_bounds
-from .placement import (allocation_policy, empty_map, last_allocation_info, map_classes, place_pair, place_pair_compact, place_pair_native, place_streams,
+from .placement import (allocation_policy, empty_map, last_allocation_info, map_classes, place_pair, place_pair_compact, place_pair_native, place_pair_shifted, place_streams,
                         set_allocation_policy)
 from .fits_io import read_header, read_map, read_map_rows, wcs_from_header, write_map
 

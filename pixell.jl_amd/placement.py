@@ -199,6 +199,89 @@ def place_pair(src_shape, dst_shape, dtype=torch.float64, device="cuda", headroo
     return src, dst, info
 
 
+def place_pair_shifted(src_shape, dst_shape, dtype=torch.float64, device="cuda", scout_gib=64, min_share=0.3, step_gib=2):
+    """(src zero-filled, dst, info): the pair in ONE allocation of exactly its own size -- no head-room kept -- whose destination
+    lies across a boundary between two memory classes.  How: a scout allocation of (pair + scout_gib) is mapped with the store
+    probe (map_classes) to find where the class boundaries lie from its start; it is returned to the driver; a ballast of the size
+    that pushes the pair's destination onto the chosen boundary is allocated in its place, the pair right after it (consecutive
+    allocations walk through the device's memory), and the ballast is returned too.  The pair's destination is then probed again:
+    at least `min_share` of its 1-GiB windows must lie in a second class, otherwise the pair is kept as it fell (and info says so).
+    Topology discovery by a fixed rule, as place_pair: nothing about the caller's kernel is timed.  Keep info["arena"] alive."""
+    import math
+    import time
+    t0 = time.perf_counter()
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    esz = torch.empty((), dtype=dtype).element_size()
+    ns, nd = math.prod(src_shape), math.prod(dst_shape)
+    al = 2 << 20
+    bs, bd = -(-ns * esz // al) * al, -(-nd * esz // al) * al
+    pair = bs + bd
+    info = {"policy": "class-aware pair: scout, ballast, exact allocation", "pair_GiB": round(pair / GiB, 2)}
+
+    def carve(arena, src_first):
+        view = arena.view(dtype)
+        so, do = (0, bs) if src_first else (bd, 0)
+        return view[so // esz: so // esz + ns].view(tuple(src_shape)), view[do // esz: do // esz + nd].view(tuple(dst_shape))
+
+    with torch.cuda.device(dev):
+        free, _t = torch.cuda.mem_get_info(dev)
+        plan = None
+        if bd >= 3 * GiB and free >= pair + 12 * GiB:
+            total = min(pair + int(scout_gib * GiB), free - 8 * GiB) // al * al
+            scout = torch.empty(total, dtype=torch.uint8, device=dev)
+            offs, labels, cinfo = map_classes(scout, step_gib=step_gib)
+            info["scout_GiB"] = round(total / GiB, 1)
+            info["probes"] = cinfo.get("probes", 0)
+            bounds = [(offs[k - 1] + offs[k] + GiB) // 2 for k in range(1, len(offs)) if labels[k] != labels[k - 1]]
+            info["boundaries_GiB_from_scout_start"] = [round(b / GiB, 1) for b in bounds]
+            # the pair's start s: destination centred on a boundary b, source below it (s = b - bs - bd/2) or above it (s = b - bd/2);
+            # the smallest ballast wins
+            cands = []
+            for b in bounds:
+                for src_first, s in ((True, b - bs - bd // 2), (False, b - bd // 2)):
+                    if s >= 0 and s + pair <= total:
+                        cands.append((s, src_first, b))
+            del scout
+            torch.cuda.empty_cache()
+            if cands:
+                plan = min(cands)
+        if plan is None:
+            arena = torch.empty(pair, dtype=torch.uint8, device=dev)
+            src, dst = carve(arena, True)
+            info.update({"placement": "plain (no boundary within the scout allocation, or a destination below 3 GiB)", "arena": arena})
+        else:
+            s, src_first, b = plan
+            s = s // al * al
+            ballast = torch.empty(s, dtype=torch.uint8, device=dev) if s >= al else None
+            arena = torch.empty(pair, dtype=torch.uint8, device=dev)
+            src, dst = carve(arena, src_first)
+            del ballast
+            torch.cuda.empty_cache()
+            # where did it fall?  (probed windows of the destination are overwritten with zeros: it is uninitialised anyway)
+            _o, dlab, dinfo = map_classes(dst.view(-1).view(torch.uint8), step_gib=1)
+            _major, share = _split_of(dlab)
+            info["probes"] = info.get("probes", 0) + dinfo.get("probes", 0)
+            info.update({"ballast_GiB": round(s / GiB, 2), "layout": "source below the destination" if src_first else "destination below the source",
+                         "destination_minor_class_share": round(share, 2), "arena": arena,
+                         "placement": "destination across a class boundary (%.0f %% of its windows in the second class)" % (100 * share)})
+            if share < min_share:
+                # the allocator did not put the pair behind the ballast (seen with ballasts of tens of GiB): the candidate search
+                # of place_pair_compact instead -- two allocations, nothing kept beyond them either
+                del src, dst, arena
+                info.pop("arena")
+                torch.cuda.empty_cache()
+                src, dst, cinfo2 = place_pair_compact(src_shape, dst_shape, dtype=dtype, device=dev, budget_gib=96)
+                info.update({"placement": "pair not behind its ballast (%.0f %% in a second class); candidate search instead: %s" % (100 * share, cinfo2.get("placement")),
+                             "source": cinfo2.get("source"), "candidates_minor_share": cinfo2.get("candidates_minor_share"), "arena": None})
+                info["seconds"] = round(time.perf_counter() - t0, 3)
+                return src, dst, info
+        src.zero_()
+    info["seconds"] = round(time.perf_counter() - t0, 3)
+    return src, dst, info
+
+
 def place_streams(shapes, dtype=torch.float64, device="cuda", headroom_gib=144, step_gib=2):
     """(tensors, info): one buffer per shape inside ONE allocation, each in a memory class of its own as far as the allocation
     has classes with room (buffer k goes into the longest free run of the class used least so far).  For kernels that write several

@@ -194,16 +194,18 @@ class DecStripReprojector(DecStripLayout):
 
     def alloc_maps(self, dtype=torch.float64, policy=None):
         """(src zero-filled, dst, info): this rank's resident source strip and its output strip, allocated by the library's policy
-        (placement.py: class-aware by default -- the destination in two memory classes, the source in another one when there is
-        one, nothing kept beyond the two maps; 'plain' = alloc_pair).  What a host that lets the library allocate gets."""
+        (placement.py: class-aware by default -- place_pair_shifted: ONE allocation of exactly the pair's size whose destination
+        lies across a class boundary, nothing kept beyond the two maps; 'plain' = alloc_pair; 'compact' = round 3's candidate search).  What a host that lets the library allocate gets."""
         from . import placement
         policy = policy or placement.allocation_policy()
         if policy == "plain":
             src, dst, arena = self.alloc_pair(dtype)
             return src, dst, {"policy": "plain", "arena": arena}
-        src, dst, info = placement.place_pair_compact(self.src_tensor_shape(), self.dst_tensor_shape(), dtype=dtype, device=self.device)
-        info["policy"] = "class-aware"
-        return src, dst, info
+        if policy == "compact":
+            src, dst, info = placement.place_pair_compact(self.src_tensor_shape(), self.dst_tensor_shape(), dtype=dtype, device=self.device)
+            info["policy"] = "class-aware (compact search)"
+            return src, dst, info
+        return placement.place_pair_shifted(self.src_tensor_shape(), self.dst_tensor_shape(), dtype=dtype, device=self.device)
 
     def alloc_pair(self, dtype=torch.float64):
         """Source and destination buffers carved out of ONE device allocation, destination above the source on a 2 MiB

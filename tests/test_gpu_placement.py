@@ -216,13 +216,36 @@ def test_strip_reprojector_alloc_maps(pj, dev):
     shape_in, wcs_in = pj.fullsky_geometry(2 * math.pi / 2400, dims=(2,))
     shape_out, wcs_out = pj.fullsky_geometry(2 * math.pi / 4800)
     sh = pj.DecStripReprojector(shape_in, wcs_in, shape_out, wcs_out, 0, 1, dev)
-    for policy in ("class-aware", "plain"):
+    for policy in ("class-aware", "compact", "plain"):
         src, dst, info = sh.alloc_maps(policy=policy)
         assert tuple(src.shape) == tuple(sh.src_tensor_shape()) and tuple(dst.shape) == tuple(sh.dst_tensor_shape())
-        assert info["policy"] == policy and float(src.abs().max()) == 0.0
+        assert info["policy"].startswith(policy if policy != "compact" else "class-aware") and float(src.abs().max()) == 0.0
         lo_s, hi_s, lo_d, hi_d = src.data_ptr(), src.data_ptr() + src.numel() * 8, dst.data_ptr(), dst.data_ptr() + dst.numel() * 8
         assert hi_s <= lo_d or hi_d <= lo_s
         del src, dst, info
+
+
+def test_place_pair_shifted_keeps_nothing_but_the_pair(pj, dev):
+    """placement.place_pair_shifted (what alloc_maps uses by default): a pair big enough to be placed (0.87 GiB source, 3.48 GiB
+    destination) comes back zero-filled / writable, non-overlapping, with its report filled in, and after the call exactly the
+    pair is allocated: the scout allocation and the ballast are back with the driver."""
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(dev)
+    sshape, dshape = (1, 5400, 21600), (1, 10801, 43200)
+    src, dst, info = pj.place_pair_shifted(sshape, dshape, device=dev, scout_gib=40)
+    assert tuple(src.shape) == sshape and tuple(dst.shape) == dshape and float(src.abs().max()) == 0.0
+    lo_s, hi_s, lo_d, hi_d = src.data_ptr(), src.data_ptr() + src.numel() * 8, dst.data_ptr(), dst.data_ptr() + dst.numel() * 8
+    assert hi_s <= lo_d or hi_d <= lo_s
+    assert "placement" in info and info["seconds"] >= 0 and info["policy"].startswith("class-aware")
+    dst.fill_(1.0)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(dev)
+    pair = (src.numel() + dst.numel()) * 8
+    assert free0 - free1 <= pair + (3 << 29), ((free0 - free1) / 2**30, info)        # 1.5 GiB: the allocator's granularity, as for place_pair_compact
+    # a pair too small to place is a plain allocation
+    s2, d2, i2 = pj.place_pair_shifted((1, 100, 200), (1, 200, 400), device=dev)
+    assert i2["placement"].startswith("plain") and float(s2.abs().max()) == 0.0
 
 
 def test_native_alloc_placed(pj, dev):

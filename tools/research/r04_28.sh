@@ -1,7 +1,7 @@
 #!/bin/bash
 # final-tree evidence for the parts that changed late in round 4: default line (plain-pair headline), one-pass unwind stats + counters
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-out=$R/gpurun_out/r04_late
+out=$R/gpurun_out/r04_late2
 mkdir -p $out
 cd $R
 S=$SECONDS; python3 bench.py > $out/bench_default.json 2> $out/bench_default.err; echo bench rc=$? seconds=$((SECONDS-S))
@@ -17,7 +17,7 @@ cp $out/stats/*/*kernel_stats.csv $out/unwind_kernel_stats.csv
 grep -A22 "k_unwind_onepass<UwSrcPix2>" $out/unwind_summary.txt | head -50
 cd $R; python3 - <<'PY'
 import json
-d=json.loads(open("gpurun_out/r04_late/bench_default.json").read().strip().splitlines()[-1])
+d=json.loads(open("gpurun_out/r04_late2/bench_default.json").read().strip().splitlines()[-1])
 print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"].get("headline_allocation_policy"), d["roofline"].get("frac_other_policies"))
 print({k:(v.get("kernel_ms_avg"),v.get("frac")) for k,v in d["configs"].items()})
 print({k:(v.get("ms"),v.get("frac")) for k,v in d["evaluators"].items()})
