@@ -1,7 +1,7 @@
 #!/bin/bash
 # final tree: whole GPU suite, default line, mosaic (one-shot / plans) with kernel stats, fuzz of every kind
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-out=$R/gpurun_out/r04_final3
+out=$R/gpurun_out/r04_final5
 mkdir -p $out
 cd $R
 timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $out/tests.txt 2>&1; rc=$?; tail -2 $out/tests.txt; [ $rc -eq 0 ] || exit $rc
@@ -15,7 +15,7 @@ cd $R
 timeout -k 10 400 python3 tools/fuzz_parity.py --seconds 240 > $out/fuzz.txt 2>&1; echo fuzz rc=$?; tail -1 $out/fuzz.txt
 python3 - <<'PY'
 import json
-d=json.loads(open("gpurun_out/r04_final3/bench_default.json").read().strip().splitlines()[-1])
+d=json.loads(open("gpurun_out/r04_final5/bench_default.json").read().strip().splitlines()[-1])
 print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"].get("headline_allocation_policy"), d["roofline"].get("frac_other_policies"))
 print({k:(v.get("kernel_ms_avg"),v.get("frac")) for k,v in d["configs"].items()})
 print({k:(v.get("ms"),v.get("frac")) for k,v in d["evaluators"].items()})
